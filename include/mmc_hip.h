@@ -1,0 +1,211 @@
+/*
+ * mmc_hip.h -- C ABI of libmmc_hip.so: the super-resolution (PDHG) solve of
+ * Multiframe Motion Coupling on AMD MI355X (gfx950).
+ *
+ * The library replaces, for one contiguous block of frames, what the reference
+ * hands to prost / flexBox inside MultiframeMotionCoupling.m:
+ *   problem assembly   init_u_prost            MultiframeMotionCoupling.m:346-574
+ *   the solve          solveU                  MultiframeMotionCoupling.m:977-1004
+ * All operators are matrix-free; nothing here builds a sparse matrix.
+ *
+ * Conventions
+ *   - Plain C, no C++ types.  Every function returns MMC_OK (0) or a negative
+ *     mmc_status; mmc_last_error() gives the message.  No exception or abort
+ *     crosses this boundary.
+ *   - All image-like host buffers are float32 in MATLAB column-major order
+ *     (row index fastest): idx = r + Ny*c + Ny*Nx*t.  The gateway converts
+ *     MATLAB doubles to float on the way in and back on the way out.
+ *   - Ny = factor*ny, Nx = factor*nx are the high-resolution frame sizes.
+ *   - A handle owns all device memory of one frame block [frame_begin,
+ *     frame_end) of a sequence of nc_global frames, plus one ghost frame at
+ *     either end when the block has a neighbour.  Calls on one handle must come
+ *     from one thread at a time.  All work is queued on one HIP stream.
+ */
+#ifndef MMC_HIP_H
+#define MMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMC_ABI_VERSION 1
+
+typedef enum mmc_status {
+    MMC_OK = 0,
+    MMC_ERR_INVALID_ARG = -1,   /* bad pointer, size or parameter combination   */
+    MMC_ERR_STATE = -2,         /* call made before its prerequisites           */
+    MMC_ERR_HIP = -3,           /* a HIP runtime call failed                    */
+    MMC_ERR_UNSUPPORTED = -4,   /* valid in the reference, not implemented here */
+    MMC_ERR_NO_DEVICE = -5      /* no usable gfx950 device                      */
+} mmc_status;
+
+/* flowDirection, MultiframeMotionCoupling.m:235, :392-398 */
+typedef enum mmc_flow_direction {
+    MMC_FLOW_FORWARD = 0,           /* 'forward'          -> constructWarpFF(v,'F-I') */
+    MMC_FLOW_BACKWARD = 1,          /* 'backward'         -> constructWarpFF(v,'I-F') */
+    MMC_FLOW_FORWARD_BACKWARD = 2   /* 'forward-backward' -> constructWarpFB(v)       */
+} mmc_flow_direction;
+
+/* interpMethod, MultiframeMotionCoupling.m:237-239, helpers/samplingOperator.m */
+typedef enum mmc_sampling {
+    MMC_SAMPLING_AVERAGE = 0,   /* 'average': block mean; exact only for factor 4 */
+    MMC_SAMPLING_STRIDE = 1     /* 'stride' : every factor-th pixel from top-left */
+} mmc_sampling;
+
+/* Versioned POD.  Set size = sizeof(mmc_params), version = MMC_ABI_VERSION. */
+typedef struct mmc_params {
+    uint32_t size;
+    uint32_t version;
+    int32_t ny, nx;            /* low-resolution frame size (rows, cols)               */
+    int32_t factor;            /* zoom factor, MultiframeMotionCoupling.m:126-130      */
+    int32_t nc_global;         /* frames in the whole sequence                         */
+    int32_t frame_begin;       /* this block is [frame_begin, frame_end), 0-based      */
+    int32_t frame_end;
+    float alpha;               /* MultiframeMotionCoupling.m:207                       */
+    float kappa;               /* :209; NaN = additive model (:515), 1 = model :500    */
+    float h;                   /* :437; <= 0: computed by mmc_init from this block     */
+    int32_t flow_direction;    /* mmc_flow_direction                                   */
+    int32_t sampling;          /* mmc_sampling                                         */
+    int32_t device;            /* HIP device ordinal                                   */
+    void *stream;              /* hipStream_t to queue on; NULL: the library makes one */
+} mmc_params;
+
+/* Result of a solve / of the last residual check. */
+typedef struct mmc_stats {
+    int32_t iterations;        /* PDHG iterations executed by this call                */
+    int32_t converged;         /* 1 if the tolerance test stopped the loop             */
+    double res_primal;         /* ||x+ - x||_2 / max(||x+||_2, tiny) at the last check */
+    double res_dual;           /* ||y+ - y||_2 / max(||y+||_2, tiny) at the last check */
+    double solve_seconds;      /* host wall time of the call, device-synchronised      */
+} mmc_stats;
+
+/* Raw sums behind mmc_stats, for all-reducing over frame blocks:
+ * [0]=sum (x+ - x)^2  [1]=sum (x+)^2  [2]=sum (y+ - y)^2  [3]=sum (y+)^2 */
+#define MMC_NUM_SUMS 4
+
+/* Progress callback, called on the calling thread after every residual check
+ * (prost's 'num_cback_calls', MultiframeMotionCoupling.m:358).  Return non-zero
+ * to stop the solve. */
+typedef int (*mmc_progress_cb)(int iteration, const mmc_stats *stats, void *user);
+
+/* Device addresses of the frames a block exchanges with its neighbours once per
+ * sweep.  Each entry is one high-resolution frame of `frame_bytes` bytes.
+ *   send_prev[2]: xbar = 2x+ - x of the FIRST local frame (u part, w part)
+ *                 -> previous block, which receives it in recv_next[2]
+ *   send_next[2]: temporal dual components (g1, g2) of the LAST local frame
+ *                 -> next block, which receives them in recv_prev[2]
+ * A pointer is NULL when the block has no neighbour on that side (or the model
+ * has no w / g2). */
+typedef struct mmc_halo {
+    uint64_t frame_bytes;
+    void *send_prev[2];
+    void *recv_next[2];
+    void *send_next[2];
+    void *recv_prev[2];
+} mmc_halo;
+
+typedef struct mmc_handle mmc_handle;
+
+int mmc_abi_version(void);
+
+/* Message of the last failure on `h`; with h == NULL the last mmc_create failure
+ * of the calling thread. */
+const char *mmc_last_error(const mmc_handle *h);
+
+/* Validates the parameters the way MultiframeMotionCoupling.init does
+ * (:228-231 positive scalars; :283-290 NaN kappa is the additive model) and
+ * allocates the device state of the block.  Replaces the variable / dual-pair
+ * declarations of init_u_prost, MultiframeMotionCoupling.m:445-459, :483. */
+int mmc_create(const mmc_params *params, mmc_handle **out);
+int mmc_destroy(mmc_handle *h);
+
+/* Low-resolution data term f: ny x nx x (frame_end-frame_begin).
+ * Replaces obj.imageSequenceSmall(:) at MultiframeMotionCoupling.m:496. */
+int mmc_set_lowres(mmc_handle *h, const float *f);
+
+/* Blur kernel k (kh x kw, column-major, both odd as helpers/RepConvMtx.m:6-8
+ * demands), applied as a true convolution with replicated border; k == NULL
+ * means no blur (MultiframeMotionCoupling.m:373).  Replaces RepConvMtx and its
+ * composition with samplingOperator, MultiframeMotionCoupling.m:368-375. */
+int mmc_set_blur(mmc_handle *h, const float *k, int kh, int kw);
+
+/* Flow fields of the pairs this block touches: global pairs
+ * [max(frame_begin-1,0), min(frame_end, nc_global-1)), laid out
+ * Ny x Nx x npairs x 2 exactly like the reference's v (helpers/constructWarpFF.m:5):
+ * component 1 = displacement along columns, component 2 = along rows, in
+ * high-resolution pixels.  occ (same pairs, Ny x Nx x npairs, non-zero =
+ * occluded, may be NULL) is the optional occlusion map of constructWarpFF.m:31-35.
+ * May be called again on a live handle to swap flows and keep the primal/dual
+ * state (variants/MultiframeMotionCouplingAlternating.m:108-159); call
+ * mmc_init again afterwards.  Replaces constructWarpFF / constructWarpFB. */
+int mmc_set_flow(mmc_handle *h, const float *v, const uint8_t *occ);
+int mmc_num_flow_pairs(const mmc_handle *h);
+
+/* Start point: u and w for the local frames followed, when the block has a
+ * next neighbour, by that neighbour's first frame (needed once, for h).
+ * w may be NULL when the model has no w (kappa = 1 or NaN).  Duals start at 0.
+ * Replaces u_vec.val / w_vec.val, MultiframeMotionCoupling.m:445-456. */
+int mmc_set_state(mmc_handle *h, const float *u, const float *w);
+int mmc_num_state_frames(const mmc_handle *h);
+
+/* Out-of-range / occlusion masks, column sums of the warp, tile source boxes,
+ * step sizes and (when params.h <= 0) h from this block's own sums.
+ * Replaces the one-off part of init_u_prost, MultiframeMotionCoupling.m:389-437. */
+int mmc_init(mmc_handle *h);
+
+/* h = (sum|W u|/M) / (sum|grad u|/M), MultiframeMotionCoupling.m:431-437:
+ * out[0] = sum |W u0| over the pairs this block owns, out[1] = sum |grad u0|
+ * over its frames, for the start point given to mmc_set_state. */
+int mmc_h_partials(mmc_handle *h, double out[2]);
+int mmc_set_h(mmc_handle *h, float value);
+int mmc_get_h(const mmc_handle *h, float *value);
+
+/* The solve: prost.solve / flexBox.runAlgorithm, MultiframeMotionCoupling.m:981,
+ * :989.  Runs at most max_iters PDHG iterations; every check_every iterations
+ * (and after the last) the residuals are reduced, the callback runs, and the
+ * loop stops if tol > 0 and max(res_primal,res_dual) < tol.  Only for a block
+ * without neighbours; blocks of a sharded sequence are driven sweep by sweep. */
+int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_every,
+              mmc_stats *stats, mmc_progress_cb cb, void *user);
+
+/* One half-iteration on local frames [t0, t1): primal update (needs recv_prev),
+ * dual update (needs recv_next).  reduce != 0 accumulates the residual sums.
+ * These are the pieces mmc_solve is made of; a sharded solve interleaves them
+ * with the halo exchange. */
+int mmc_sweep_primal(mmc_handle *h, int t0, int t1, int reduce);
+int mmc_sweep_dual(mmc_handle *h, int t0, int t1, int reduce);
+int mmc_sums_reset(mmc_handle *h);
+int mmc_sums_read(mmc_handle *h, double out[MMC_NUM_SUMS]);   /* synchronises */
+int mmc_halo_info(mmc_handle *h, mmc_halo *out);
+int mmc_sync(mmc_handle *h);
+
+/* Result extraction, MultiframeMotionCoupling.m:983-986: u and w of the local
+ * frames (w may be NULL). */
+int mmc_get_state(mmc_handle *h, float *u, float *w);
+
+/* Primal objective of the current iterate restricted to this block:
+ * ||A u - f||_1 + regulariser, for logging (the quantity prost prints). */
+int mmc_energy(mmc_handle *h, double *value);
+
+/* ---- Test hooks: the operators of the sweeps without the prox maps. ---------
+ * K x for x = (u, w): out_p is n*L, out_g1/out_g2 are component-major
+ * [temporal; dx; dy] of N*L each (additive model: g1 = temporal only,
+ * g2 = [dx; dy]).  Input frames as for mmc_set_state. */
+int mmc_debug_apply_K(mmc_handle *h, const float *u, const float *w,
+                      float *out_p, float *out_g1, float *out_g2);
+/* K' y: p is n*L, g1/g2 as above, plus the previous block's temporal duals
+ * (ghost, may be NULL). */
+int mmc_debug_apply_KT(mmc_handle *h, const float *p, const float *g1, const float *g2,
+                       const float *ghost_g1t, const float *ghost_g2t,
+                       float *out_u, float *out_w);
+/* Diagonal step sizes: tau for u, w (N*L each) and sigma for p (n*L), g1, g2
+ * (N*L each, one per pixel group). */
+int mmc_debug_steps(mmc_handle *h, float *tau_u, float *tau_w,
+                    float *sigma_p, float *sigma_g1, float *sigma_g2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMC_HIP_H */

@@ -1,0 +1,20 @@
+"""MI355X-native super-resolution solve of Multiframe Motion Coupling.
+
+Host-side mirror of the reference's MultiframeMotionCoupling class over the
+libmmc_hip C ABI (HIP kernels for gfx950).  Importing this package does not
+load the native library; constructing a solver does, and fails loudly if the
+library has not been built.
+"""
+from ._capi import MMCError  # noqa: F401
+
+__all__ = ["MMCError", "FrameBlockSolver", "MultiframeMotionCoupling"]
+
+
+def __getattr__(name):
+    if name == "FrameBlockSolver":
+        from .solver import FrameBlockSolver
+        return FrameBlockSolver
+    if name == "MultiframeMotionCoupling":
+        from .mmc import MultiframeMotionCoupling
+        return MultiframeMotionCoupling
+    raise AttributeError(name)

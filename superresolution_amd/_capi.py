@@ -1,0 +1,118 @@
+"""ctypes binding of libmmc_hip.so (include/mmc_hip.h).
+
+This is the stand-in for the MEX gateway: it hands raw column-major float32
+buffers to the C ABI exactly as mex/mmc_hip_mex.cpp does.  There is no CPU
+fallback: if the library is missing or fails to load, importing the solver
+raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+
+MMC_ABI_VERSION = 1
+MMC_NUM_SUMS = 4
+
+FLOW_FORWARD, FLOW_BACKWARD, FLOW_FORWARD_BACKWARD = 0, 1, 2
+SAMPLING_AVERAGE, SAMPLING_STRIDE = 0, 1
+
+STATUS_NAMES = {0: "MMC_OK", -1: "MMC_ERR_INVALID_ARG", -2: "MMC_ERR_STATE", -3: "MMC_ERR_HIP",
+                -4: "MMC_ERR_UNSUPPORTED", -5: "MMC_ERR_NO_DEVICE"}
+
+
+class MMCError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+        self.message = message
+
+
+class mmc_params(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("version", C.c_uint32),
+                ("ny", C.c_int32), ("nx", C.c_int32), ("factor", C.c_int32),
+                ("nc_global", C.c_int32), ("frame_begin", C.c_int32), ("frame_end", C.c_int32),
+                ("alpha", C.c_float), ("kappa", C.c_float), ("h", C.c_float),
+                ("flow_direction", C.c_int32), ("sampling", C.c_int32), ("device", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+class mmc_stats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
+                ("res_primal", C.c_double), ("res_dual", C.c_double), ("solve_seconds", C.c_double)]
+
+
+class mmc_halo(C.Structure):
+    _fields_ = [("frame_bytes", C.c_uint64),
+                ("send_prev", C.c_void_p * 2), ("recv_next", C.c_void_p * 2),
+                ("send_next", C.c_void_p * 2), ("recv_prev", C.c_void_p * 2)]
+
+
+PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(mmc_stats), C.c_void_p)
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_H = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/mmc_hip.h declares
+SIGNATURES = {
+    "mmc_abi_version": (C.c_int, []),
+    "mmc_last_error": (C.c_char_p, [_H]),
+    "mmc_create": (C.c_int, [C.POINTER(mmc_params), C.POINTER(_H)]),
+    "mmc_destroy": (C.c_int, [_H]),
+    "mmc_set_lowres": (C.c_int, [_H, _fp]),
+    "mmc_set_blur": (C.c_int, [_H, _fp, C.c_int, C.c_int]),
+    "mmc_set_flow": (C.c_int, [_H, _fp, _u8p]),
+    "mmc_num_flow_pairs": (C.c_int, [_H]),
+    "mmc_set_state": (C.c_int, [_H, _fp, _fp]),
+    "mmc_num_state_frames": (C.c_int, [_H]),
+    "mmc_init": (C.c_int, [_H]),
+    "mmc_h_partials": (C.c_int, [_H, _dp]),
+    "mmc_set_h": (C.c_int, [_H, C.c_float]),
+    "mmc_get_h": (C.c_int, [_H, _fp]),
+    "mmc_solve": (C.c_int, [_H, C.c_int, C.c_float, C.c_int, C.POINTER(mmc_stats), PROGRESS_CB, C.c_void_p]),
+    "mmc_sweep_primal": (C.c_int, [_H, C.c_int, C.c_int, C.c_int]),
+    "mmc_sweep_dual": (C.c_int, [_H, C.c_int, C.c_int, C.c_int]),
+    "mmc_sums_reset": (C.c_int, [_H]),
+    "mmc_sums_read": (C.c_int, [_H, _dp]),
+    "mmc_halo_info": (C.c_int, [_H, C.POINTER(mmc_halo)]),
+    "mmc_sync": (C.c_int, [_H]),
+    "mmc_get_state": (C.c_int, [_H, _fp, _fp]),
+    "mmc_energy": (C.c_int, [_H, _dp]),
+    "mmc_debug_apply_K": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),
+    "mmc_debug_apply_KT": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "mmc_debug_steps": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libmmc_hip.so and attach the prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("libmmc_hip.so not found at %s -- build it with "
+                          "`python -m superresolution_amd.build` (there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mmc_abi_version() != MMC_ABI_VERSION:
+        raise ImportError("libmmc_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def as_f32(x):
+    """Column-major float32 copy of x (what the MEX gateway hands over)."""
+    return np.asfortranarray(np.asarray(x), dtype=np.float32)
+
+
+def fptr(a):
+    return None if a is None else a.ctypes.data_as(_fp)

@@ -1,0 +1,671 @@
+// C ABI of libmmc_hip.so (see include/mmc_hip.h): handle management, input
+// validation in the spirit of MultiframeMotionCoupling.init, the one-off
+// set-up that replaces init_u_prost's sparse-matrix construction, and the
+// PDHG loop that replaces prost.solve / flexBox.runAlgorithm.
+#include "../../include/mmc_hip.h"
+#include "mmc_internal.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits.h>
+#include <string>
+#include <vector>
+
+struct mmc_handle {
+    mmc_params prm;
+    Geom g;
+    Arrays a;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int L = 0, has_prev = 0, has_next = 0;
+    int pair_lo = 0, npairs = 0;          // global pairs [pair_lo, pair_lo+npairs) this block touches
+    std::vector<float> blur;              // kh x kw column-major; empty = no blur
+    int kh = 1, kw = 1;
+    bool have_f = false, have_flow = false, have_state = false, inited = false, have_h = false;
+    float h = 1.f;
+    std::vector<void *> allocs;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(mmc_handle *h, int code, const std::string &msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail((h), MMC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define REQUIRE_HANDLE(h) do { if (!(h)) return MMC_ERR_INVALID_ARG; } while (0)
+
+static size_t frame_slots(const mmc_handle *h) { return (size_t)h->L + 2; }
+
+template <typename T>
+static int dev_alloc(mmc_handle *h, T **ptr, size_t count, bool zero = true) {
+    void *p = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIPCHK(h, hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    if (zero) HIPCHK(h, hipMemsetAsync(p, 0, bytes, h->stream));
+    *ptr = (T *)p;
+    return MMC_OK;
+}
+
+extern "C" int mmc_abi_version(void) { return MMC_ABI_VERSION; }
+
+extern "C" const char *mmc_last_error(const mmc_handle *h) {
+    return h ? h->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
+    if (!p || !out) return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: null argument");
+    *out = nullptr;
+    if (p->size != sizeof(mmc_params) || p->version != MMC_ABI_VERSION)
+        return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: params size/version mismatch");
+    // MultiframeMotionCoupling.m:228-231 checkposScalar
+    if (!(p->factor > 0)) return fail(nullptr, MMC_ERR_INVALID_ARG, "Input must be > 0 (factor)");
+    if (!(p->alpha > 0.f)) return fail(nullptr, MMC_ERR_INVALID_ARG, "Input must be > 0 (alpha)");
+    if (!std::isnan(p->kappa) && !(p->kappa > 0.f))
+        return fail(nullptr, MMC_ERR_INVALID_ARG, "Input must be > 0 (kappa)");
+    if (p->ny <= 0 || p->nx <= 0) return fail(nullptr, MMC_ERR_INVALID_ARG, "Load an actual video sequence (empty frame)");
+    if (p->nc_global <= 0 || p->frame_begin < 0 || p->frame_end > p->nc_global || p->frame_end <= p->frame_begin)
+        return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: frame block must be a non-empty range inside [0, nc_global)");
+    if (p->flow_direction < 0 || p->flow_direction > 2)
+        return fail(nullptr, MMC_ERR_INVALID_ARG, "Invalid flow direction.");
+    if (p->sampling != MMC_SAMPLING_AVERAGE && p->sampling != MMC_SAMPLING_STRIDE)
+        return fail(nullptr, MMC_ERR_UNSUPPORTED, "interpMethod: only 'average' and 'stride' are implemented");
+    if (p->sampling == MMC_SAMPLING_AVERAGE && p->factor != 4)
+        return fail(nullptr, MMC_ERR_UNSUPPORTED,
+                    "interpMethod 'average' is a block mean only for factor 4 (samplingOperator.m:70-73); other factors are not implemented");
+    if ((long long)p->ny * p->factor * (long long)p->nx * p->factor > (long long)INT_MAX / 4)
+        return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: frame too large for 32-bit pixel indexing");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, MMC_ERR_NO_DEVICE, "mmc_create: no HIP device available");
+    if (p->device < 0 || p->device >= ndev)
+        return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: device ordinal out of range");
+
+    mmc_handle *h = new mmc_handle();
+    h->prm = *p;
+    auto bail = [&](int code) {
+        g_create_err = h->err;
+        mmc_destroy(h);
+        return code;
+    };
+    if (hipSetDevice(p->device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MMC_ERR_HIP); }
+    if (p->stream) {
+        h->stream = (hipStream_t)p->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            h->err = "hipStreamCreate failed";
+            return bail(MMC_ERR_HIP);
+        }
+        h->own_stream = true;
+    }
+    h->L = p->frame_end - p->frame_begin;
+    h->has_prev = p->frame_begin > 0;
+    h->has_next = p->frame_end < p->nc_global;
+    h->pair_lo = p->frame_begin > 0 ? p->frame_begin - 1 : 0;
+    {
+        int hi = p->frame_end < p->nc_global - 1 ? p->frame_end : p->nc_global - 1;
+        h->npairs = hi > h->pair_lo ? hi - h->pair_lo : 0;
+    }
+
+    Geom &g = h->g;
+    memset(&g, 0, sizeof(g));
+    g.ny = p->ny; g.nx = p->nx; g.n = p->ny * p->nx;
+    g.f = p->factor;
+    g.Ny = p->ny * p->factor; g.Nx = p->nx * p->factor; g.N = g.Ny * g.Nx;
+    g.L = h->L; g.frame_begin = p->frame_begin; g.nc_global = p->nc_global;
+    g.dir = p->flow_direction;
+    g.alpha = p->alpha;
+    if (std::isnan(p->kappa)) { g.model = MODEL_ADD; g.kappa = 1.f; g.radius1 = p->alpha; g.radius2 = p->alpha; }
+    else if (p->kappa == 1.f) { g.model = MODEL_K1; g.kappa = 1.f; g.radius1 = 2.f * p->alpha; g.radius2 = 0.f; }
+    else { g.model = MODEL_IC; g.kappa = p->kappa; g.radius1 = p->alpha; g.radius2 = p->alpha; }
+    g.tiles_r = (g.Ny + TILE_R - 1) / TILE_R;
+    g.tiles_c = (g.Nx + TILE_C - 1) / TILE_C;
+    g.ntiles = g.tiles_r * g.tiles_c;
+    g.inv_h = 1.f;
+    if (p->h > 0.f) { h->h = p->h; h->have_h = true; g.inv_h = 1.f / p->h; }
+
+    Arrays &a = h->a;
+    memset(&a, 0, sizeof(a));
+    const size_t fs = frame_slots(h) * (size_t)g.N;
+    float **per_px[] = {&a.u, &a.w, &a.ub, &a.wb, &a.g1t, &a.g1x, &a.g1y, &a.g2t, &a.g2x, &a.g2y, &a.vx, &a.vy, &a.cW};
+    for (float **pp : per_px) {
+        int rc = dev_alloc(h, pp, fs);
+        if (rc != MMC_OK) return bail(rc);
+    }
+    int rc;
+    if ((rc = dev_alloc(h, &a.p, (size_t)h->L * g.n)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.f, (size_t)h->L * g.n)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.cA, (size_t)g.N)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.sigp, (size_t)g.n)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.bbox, (size_t)(h->L + 1) * g.ntiles * 4)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)) != MMC_OK) return bail(rc);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MMC_ERR_HIP); }
+    *out = h;
+    return MMC_OK;
+}
+
+extern "C" int mmc_destroy(mmc_handle *h) {
+    if (!h) return MMC_OK;
+    hipSetDevice(h->prm.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return MMC_OK;
+}
+
+static int use_device(mmc_handle *h) {
+    HIPCHK(h, hipSetDevice(h->prm.device));
+    return MMC_OK;
+}
+
+extern "C" int mmc_set_lowres(mmc_handle *h, const float *f) {
+    REQUIRE_HANDLE(h);
+    if (!f) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_lowres: null data");
+    int rc = use_device(h); if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->a.f, f, (size_t)h->L * h->g.n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_f = true;
+    return MMC_OK;
+}
+
+extern "C" int mmc_set_blur(mmc_handle *h, const float *k, int kh, int kw) {
+    REQUIRE_HANDLE(h);
+    if (!k) { h->blur.clear(); h->kh = h->kw = 1; h->inited = false; return MMC_OK; }
+    // helpers/RepConvMtx.m:6-8
+    if (kh <= 0 || kw <= 0 || (kh % 2) != 1 || (kw % 2) != 1)
+        return fail(h, MMC_ERR_INVALID_ARG, "kernel has even dimensions (which is not implemented)");
+    const int td = h->prm.sampling == MMC_SAMPLING_AVERAGE ? h->prm.factor : 1;
+    if (kh + td - 1 > MMC_MAX_CK || kw + td - 1 > MMC_MAX_CK)
+        return fail(h, MMC_ERR_UNSUPPORTED, "mmc_set_blur: blur kernel too large");
+    h->blur.assign(k, k + (size_t)kh * kw);
+    h->kh = kh; h->kw = kw;
+    h->inited = false;
+    return MMC_OK;
+}
+
+extern "C" int mmc_num_flow_pairs(const mmc_handle *h) { return h ? h->npairs : MMC_ERR_INVALID_ARG; }
+extern "C" int mmc_num_state_frames(const mmc_handle *h) { return h ? h->L + h->has_next : MMC_ERR_INVALID_ARG; }
+
+extern "C" int mmc_set_flow(mmc_handle *h, const float *v, const uint8_t *occ) {
+    REQUIRE_HANDLE(h);
+    int rc = use_device(h); if (rc) return rc;
+    const Geom &g = h->g;
+    if (h->npairs > 0) {
+        if (!v) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_flow: null flow");
+        // pair with global index gq lives in frame slot (gq - frame_begin) + 1
+        const size_t slot0 = (size_t)(h->pair_lo - g.frame_begin + 1);
+        const size_t cnt = (size_t)h->npairs * g.N;
+        float *dvx = h->a.vx + slot0 * g.N, *dvy = h->a.vy + slot0 * g.N;
+        HIPCHK(h, hipMemcpyAsync(dvx, v, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(dvy, v + cnt, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if (occ) {
+            uint8_t *docc = nullptr;
+            HIPCHK(h, hipMalloc((void **)&docc, cnt));
+            hipError_t e = hipMemcpyAsync(docc, occ, cnt, hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = mmc_launch_fold_occ(g, dvx, docc, cnt, h->stream);
+            hipError_t e2 = hipStreamSynchronize(h->stream);
+            hipFree(docc);
+            HIPCHK(h, e);
+            HIPCHK(h, e2);
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->have_flow = true;
+    h->inited = false;
+    return MMC_OK;
+}
+
+extern "C" int mmc_set_state(mmc_handle *h, const float *u, const float *w) {
+    REQUIRE_HANDLE(h);
+    int rc = use_device(h); if (rc) return rc;
+    const Geom &g = h->g;
+    if (!u) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_state: null u");
+    if (g.model == MODEL_IC && !w) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_state: this model needs w");
+    const size_t nloc = (size_t)h->L * g.N, nall = (size_t)(h->L + h->has_next) * g.N;
+    Arrays &a = h->a;
+    HIPCHK(h, hipMemcpyAsync(a.u + g.N, u, nloc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(a.ub + g.N, u, nall * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (g.model == MODEL_IC) {
+        HIPCHK(h, hipMemcpyAsync(a.w + g.N, w, nloc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(a.wb + g.N, w, nall * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    // duals start at zero
+    const size_t fs = frame_slots(h) * (size_t)g.N * sizeof(float);
+    float *duals[] = {a.g1t, a.g1x, a.g1y, a.g2t, a.g2x, a.g2y};
+    for (float *d : duals) HIPCHK(h, hipMemsetAsync(d, 0, fs, h->stream));
+    HIPCHK(h, hipMemsetAsync(a.p, 0, (size_t)h->L * g.n * sizeof(float), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_state = true;
+    return MMC_OK;
+}
+
+// Composite kernel of (sampling taps) * (flipped blur), and the abs row / column
+// sums of A = D*B with the replicate border of RepConvMtx.m:23-32 merged.
+static int build_data_operator(mmc_handle *h) {
+    Geom &g = h->g;
+    const int td = h->prm.sampling == MMC_SAMPLING_AVERAGE ? g.f : 1;
+    const double wd = 1.0 / td;
+    const int kh = h->kh, kw = h->kw;
+    g.CH = td + kh - 1; g.CW = td + kw - 1;
+    g.oy = -(kh / 2); g.ox = -(kw / 2);
+    if (g.f * (g.ny - 1) + td - 1 > g.Ny - 1 || g.f * (g.nx - 1) + td - 1 > g.Nx - 1)
+        return fail(h, MMC_ERR_UNSUPPORTED, "sampling window leaves the image");
+    std::vector<double> ck((size_t)g.CH * g.CW, 0.0);
+    for (int b = 0; b < td; ++b)
+        for (int aa = 0; aa < td; ++aa)
+            for (int j = 0; j < kw; ++j)
+                for (int i = 0; i < kh; ++i) {
+                    // flipped kernel: true convolution, RepConvMtx.m:33
+                    double kv = h->blur.empty() ? 1.0 : (double)h->blur[(size_t)(kh - 1 - i) + (size_t)kh * (kw - 1 - j)];
+                    ck[(size_t)(aa + i) + (size_t)g.CH * (b + j)] += wd * wd * kv;
+                }
+    std::vector<float> ckf(ck.begin(), ck.end());
+    std::vector<double> colsum((size_t)g.N, 0.0);
+    std::vector<float> sig((size_t)g.n);
+    std::vector<double> merged((size_t)g.CH * g.CW);
+    for (int C = 0; C < g.nx; ++C)
+        for (int R = 0; R < g.ny; ++R) {
+            // merge taps that clamp onto the same pixel before taking |.|
+            const int rbase = g.f * R + g.oy, cbase = g.f * C + g.ox;
+            const bool border = rbase < 0 || cbase < 0 || rbase + g.CH > g.Ny || cbase + g.CW > g.Nx;
+            double rowsum = 0.0;
+            if (!border) {
+                for (int nn = 0; nn < g.CW; ++nn)
+                    for (int mm = 0; mm < g.CH; ++mm) {
+                        const double v = std::fabs((double)ckf[(size_t)mm + (size_t)g.CH * nn]);
+                        rowsum += v;
+                        colsum[(size_t)(rbase + mm) + (size_t)g.Ny * (cbase + nn)] += v;
+                    }
+            } else {
+                std::fill(merged.begin(), merged.end(), 0.0);
+                const int rlo = std::min(std::max(rbase, 0), g.Ny - 1), clo = std::min(std::max(cbase, 0), g.Nx - 1);
+                for (int nn = 0; nn < g.CW; ++nn)
+                    for (int mm = 0; mm < g.CH; ++mm) {
+                        const int rr = std::min(std::max(rbase + mm, 0), g.Ny - 1);
+                        const int cc = std::min(std::max(cbase + nn, 0), g.Nx - 1);
+                        merged[(size_t)(rr - rlo) + (size_t)g.CH * (cc - clo)] += (double)ckf[(size_t)mm + (size_t)g.CH * nn];
+                    }
+                for (int nn = 0; nn < g.CW; ++nn)
+                    for (int mm = 0; mm < g.CH; ++mm) {
+                        const double v = std::fabs(merged[(size_t)mm + (size_t)g.CH * nn]);
+                        if (v == 0.0) continue;
+                        rowsum += v;
+                        colsum[(size_t)(rlo + mm) + (size_t)g.Ny * (clo + nn)] += v;
+                    }
+            }
+            sig[(size_t)R + (size_t)g.ny * C] = rowsum > 0.0 ? (float)(1.0 / rowsum) : 1.f;
+        }
+    std::vector<float> colf(colsum.begin(), colsum.end());
+    HIPCHK(h, hipMemcpyAsync(h->a.cker, ckf.data(), ckf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->a.cA, colf.data(), colf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->a.sigp, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MMC_OK;
+}
+
+static int read_sums(mmc_handle *h, int first, int count, double *out) {
+    std::vector<double> host((size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS);
+    HIPCHK(h, hipMemcpyAsync(host.data(), h->a.sums, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < count; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < MMC_SUM_SLOTS; ++k) s += host[(size_t)(first + i) * MMC_SUM_SLOTS + k];
+        out[i] = s;
+    }
+    return MMC_OK;
+}
+
+static int zero_sums(mmc_handle *h) {
+    HIPCHK(h, hipMemsetAsync(h->a.sums, 0, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS * sizeof(double), h->stream));
+    return MMC_OK;
+}
+
+extern "C" int mmc_h_partials(mmc_handle *h, double out[2]) {
+    REQUIRE_HANDLE(h);
+    if (!out) return fail(h, MMC_ERR_INVALID_ARG, "mmc_h_partials: null output");
+    if (!h->have_state || !h->have_flow) return fail(h, MMC_ERR_STATE, "mmc_h_partials: set the flow and the start point first");
+    int rc = use_device(h); if (rc) return rc;
+    if ((rc = zero_sums(h))) return rc;
+    HIPCHK(h, mmc_launch_h_partials(h->g, h->a, h->stream));
+    return read_sums(h, 6, 2, out);
+}
+
+extern "C" int mmc_set_h(mmc_handle *h, float value) {
+    REQUIRE_HANDLE(h);
+    if (!(value > 0.f) || !std::isfinite(value)) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_h: h must be positive and finite");
+    h->h = value; h->have_h = true; h->g.inv_h = 1.f / value;
+    return MMC_OK;
+}
+
+extern "C" int mmc_get_h(const mmc_handle *h, float *value) {
+    if (!h || !value) return MMC_ERR_INVALID_ARG;
+    *value = h->h;
+    return MMC_OK;
+}
+
+extern "C" int mmc_init(mmc_handle *h) {
+    REQUIRE_HANDLE(h);
+    if (!h->have_f) return fail(h, MMC_ERR_STATE, "mmc_init: no low-resolution data (mmc_set_lowres)");
+    if (!h->have_flow && h->npairs > 0) return fail(h, MMC_ERR_STATE, "mmc_init: no flow field (mmc_set_flow)");
+    if (!h->have_state) return fail(h, MMC_ERR_STATE, "mmc_init: no start point (mmc_set_state)");
+    int rc = use_device(h); if (rc) return rc;
+    if ((rc = build_data_operator(h))) return rc;
+    const Geom &g = h->g;
+    Arrays &a = h->a;
+    HIPCHK(h, hipMemsetAsync(a.cW, 0, frame_slots(h) * (size_t)g.N * sizeof(float), h->stream));
+    {
+        std::vector<int> bb((size_t)(h->L + 1) * g.ntiles * 4);
+        for (size_t i = 0; i < bb.size(); i += 4) { bb[i] = INT_MAX; bb[i + 1] = -1; bb[i + 2] = INT_MAX; bb[i + 3] = -1; }
+        HIPCHK(h, hipMemcpyAsync(a.bbox, bb.data(), bb.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(h, mmc_launch_init_warp(g, a, h->stream));
+    HIPCHK(h, mmc_launch_sanitize(g, a, h->stream));
+    if (!h->have_h) {
+        // MultiframeMotionCoupling.m:431-437, from this block's own sums
+        double s[2];
+        if ((rc = mmc_h_partials(h, s))) return rc;
+        if (g.nc_global == 1) {
+            h->h = 1.f;
+        } else {
+            if (!(s[0] > 0.0) || !(s[1] > 0.0))
+                return fail(h, MMC_ERR_INVALID_ARG,
+                            "mmc_init: warp or gradient energy of the start point is zero, h = warpPix/gradPix is undefined; pass h explicitly");
+            h->h = (float)(s[0] / s[1]);
+        }
+        h->have_h = true;
+        h->g.inv_h = 1.f / h->h;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->inited = true;
+    return MMC_OK;
+}
+
+static int check_range(mmc_handle *h, int t0, int t1) {
+    if (!h->inited) return fail(h, MMC_ERR_STATE, "No initialization found, run mmc_init first.");
+    if (t0 < 0 || t1 > h->L || t1 < t0) return fail(h, MMC_ERR_INVALID_ARG, "sweep: frame range outside the block");
+    return MMC_OK;
+}
+
+extern "C" int mmc_sweep_primal(mmc_handle *h, int t0, int t1, int reduce) {
+    REQUIRE_HANDLE(h);
+    int rc = check_range(h, t0, t1); if (rc) return rc;
+    if ((rc = use_device(h))) return rc;
+    HIPCHK(h, mmc_launch_primal(h->g, h->a, t0, t1, MODE_UPDATE, reduce != 0, h->stream));
+    return MMC_OK;
+}
+
+extern "C" int mmc_sweep_dual(mmc_handle *h, int t0, int t1, int reduce) {
+    REQUIRE_HANDLE(h);
+    int rc = check_range(h, t0, t1); if (rc) return rc;
+    if ((rc = use_device(h))) return rc;
+    HIPCHK(h, mmc_launch_dual(h->g, h->a, t0, t1, MODE_UPDATE, reduce != 0, h->stream));
+    return MMC_OK;
+}
+
+extern "C" int mmc_sums_reset(mmc_handle *h) {
+    REQUIRE_HANDLE(h);
+    int rc = use_device(h); if (rc) return rc;
+    return zero_sums(h);
+}
+
+extern "C" int mmc_sums_read(mmc_handle *h, double out[MMC_NUM_SUMS]) {
+    REQUIRE_HANDLE(h);
+    if (!out) return fail(h, MMC_ERR_INVALID_ARG, "mmc_sums_read: null output");
+    int rc = use_device(h); if (rc) return rc;
+    return read_sums(h, 0, MMC_NUM_SUMS, out);
+}
+
+extern "C" int mmc_sync(mmc_handle *h) {
+    REQUIRE_HANDLE(h);
+    int rc = use_device(h); if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MMC_OK;
+}
+
+extern "C" int mmc_halo_info(mmc_handle *h, mmc_halo *out) {
+    REQUIRE_HANDLE(h);
+    if (!out) return fail(h, MMC_ERR_INVALID_ARG, "mmc_halo_info: null output");
+    const Geom &g = h->g;
+    const Arrays &a = h->a;
+    memset(out, 0, sizeof(*out));
+    out->frame_bytes = (uint64_t)g.N * sizeof(float);
+    const bool ic = g.model == MODEL_IC;
+    const size_t N = (size_t)g.N;
+    if (h->has_prev) {
+        out->send_prev[0] = a.ub + N;                       // first local frame
+        out->send_prev[1] = ic ? a.wb + N : nullptr;
+        out->recv_prev[0] = a.g1t;                          // ghost slot of pair -1
+        out->recv_prev[1] = ic ? a.g2t : nullptr;
+    }
+    if (h->has_next) {
+        out->recv_next[0] = a.ub + N * (size_t)(h->L + 1);  // ghost slot of frame L
+        out->recv_next[1] = ic ? a.wb + N * (size_t)(h->L + 1) : nullptr;
+        out->send_next[0] = a.g1t + N * (size_t)h->L;       // last local pair
+        out->send_next[1] = ic ? a.g2t + N * (size_t)h->L : nullptr;
+    }
+    return MMC_OK;
+}
+
+static void fill_stats(mmc_stats *st, const double s[MMC_NUM_SUMS]) {
+    const double tiny = 1e-30;
+    st->res_primal = std::sqrt(s[0]) / std::max(std::sqrt(s[1]), tiny);
+    st->res_dual = std::sqrt(s[2]) / std::max(std::sqrt(s[3]), tiny);
+}
+
+extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_every,
+                         mmc_stats *stats, mmc_progress_cb cb, void *user) {
+    REQUIRE_HANDLE(h);
+    if (!h->inited) return fail(h, MMC_ERR_STATE, "No initialization found, run mmc_init first.");
+    if (h->has_prev || h->has_next)
+        return fail(h, MMC_ERR_STATE, "mmc_solve: this block has neighbours; drive it with mmc_sweep_* and the halo exchange");
+    if (max_iters < 0) return fail(h, MMC_ERR_INVALID_ARG, "mmc_solve: negative iteration count");
+    if (check_every <= 0) check_every = max_iters > 0 ? max_iters : 1;
+    int rc = use_device(h); if (rc) return rc;
+    mmc_stats st;
+    memset(&st, 0, sizeof(st));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const auto t_start = std::chrono::steady_clock::now();
+    const Geom &g = h->g;
+    for (int it = 0; it < max_iters; ++it) {
+        const bool check = ((it + 1) % check_every == 0) || it == max_iters - 1;
+        if (check && (rc = zero_sums(h))) return rc;
+        HIPCHK(h, mmc_launch_primal(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream));
+        HIPCHK(h, mmc_launch_dual(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream));
+        st.iterations = it + 1;
+        if (check) {
+            double s[MMC_NUM_SUMS];
+            if ((rc = read_sums(h, 0, MMC_NUM_SUMS, s))) return rc;
+            fill_stats(&st, s);
+            st.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            if (cb && cb(st.iterations, &st, user)) break;
+            if (tol > 0.f && st.res_primal < tol && st.res_dual < tol) { st.converged = 1; break; }
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    st.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (stats) *stats = st;
+    return MMC_OK;
+}
+
+extern "C" int mmc_get_state(mmc_handle *h, float *u, float *w) {
+    REQUIRE_HANDLE(h);
+    if (!h->have_state) return fail(h, MMC_ERR_STATE, "mmc_get_state: no state");
+    int rc = use_device(h); if (rc) return rc;
+    const Geom &g = h->g;
+    const size_t nloc = (size_t)h->L * g.N * sizeof(float);
+    if (u) HIPCHK(h, hipMemcpyAsync(u, h->a.u + g.N, nloc, hipMemcpyDeviceToHost, h->stream));
+    if (w) {
+        if (g.model != MODEL_IC) return fail(h, MMC_ERR_INVALID_ARG, "mmc_get_state: this model has no w");
+        HIPCHK(h, hipMemcpyAsync(w, h->a.w + g.N, nloc, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MMC_OK;
+}
+
+extern "C" int mmc_energy(mmc_handle *h, double *value) {
+    REQUIRE_HANDLE(h);
+    if (!value) return fail(h, MMC_ERR_INVALID_ARG, "mmc_energy: null output");
+    if (!h->inited) return fail(h, MMC_ERR_STATE, "No initialization found, run mmc_init first.");
+    if (h->has_next) return fail(h, MMC_ERR_UNSUPPORTED, "mmc_energy: only for a block without a next neighbour");
+    int rc = use_device(h); if (rc) return rc;
+    if ((rc = zero_sums(h))) return rc;
+    Arrays e = h->a;
+    e.ub = h->a.u; e.wb = h->a.w;     // evaluate at the iterate, not at xbar
+    HIPCHK(h, mmc_launch_dual(h->g, e, 0, h->L, MODE_ENERGY, false, h->stream));
+    double s[2];
+    if ((rc = read_sums(h, 4, 2, s))) return rc;
+    *value = s[0] + s[1];
+    return MMC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// test hooks
+// ---------------------------------------------------------------------------
+
+static int zero_duals(mmc_handle *h) {
+    const Geom &g = h->g;
+    Arrays &a = h->a;
+    const size_t fs = frame_slots(h) * (size_t)g.N * sizeof(float);
+    float *duals[] = {a.g1t, a.g1x, a.g1y, a.g2t, a.g2x, a.g2y};
+    for (float *d : duals) HIPCHK(h, hipMemsetAsync(d, 0, fs, h->stream));
+    HIPCHK(h, hipMemsetAsync(a.p, 0, (size_t)h->L * g.n * sizeof(float), h->stream));
+    return MMC_OK;
+}
+
+static int restore_xbar(mmc_handle *h) {
+    const Geom &g = h->g;
+    Arrays &a = h->a;
+    const size_t nloc = (size_t)h->L * g.N * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(a.ub + g.N, a.u + g.N, nloc, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(a.wb + g.N, a.w + g.N, nloc, hipMemcpyDeviceToDevice, h->stream));
+    return MMC_OK;
+}
+
+static int download_dual(mmc_handle *h, float *out_g1, float *out_g2) {
+    const Geom &g = h->g;
+    const Arrays &a = h->a;
+    const size_t M = (size_t)h->L * g.N, B = M * sizeof(float);
+    const size_t o = (size_t)g.N;
+    if (g.model == MODEL_ADD) {
+        if (out_g1) HIPCHK(h, hipMemcpyAsync(out_g1, a.g1t + o, B, hipMemcpyDeviceToHost, h->stream));
+        if (out_g2) {
+            HIPCHK(h, hipMemcpyAsync(out_g2, a.g1x + o, B, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(out_g2 + M, a.g1y + o, B, hipMemcpyDeviceToHost, h->stream));
+        }
+    } else {
+        if (out_g1) {
+            HIPCHK(h, hipMemcpyAsync(out_g1, a.g1t + o, B, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(out_g1 + M, a.g1x + o, B, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(out_g1 + 2 * M, a.g1y + o, B, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (out_g2 && g.model == MODEL_IC) {
+            HIPCHK(h, hipMemcpyAsync(out_g2, a.g2t + o, B, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(out_g2 + M, a.g2x + o, B, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(out_g2 + 2 * M, a.g2y + o, B, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    return MMC_OK;
+}
+
+extern "C" int mmc_debug_apply_K(mmc_handle *h, const float *u, const float *w,
+                                 float *out_p, float *out_g1, float *out_g2) {
+    REQUIRE_HANDLE(h);
+    if (!h->inited) return fail(h, MMC_ERR_STATE, "No initialization found, run mmc_init first.");
+    if (!u) return fail(h, MMC_ERR_INVALID_ARG, "mmc_debug_apply_K: null u");
+    int rc = use_device(h); if (rc) return rc;
+    const Geom &g = h->g;
+    Arrays &a = h->a;
+    const size_t nall = (size_t)(h->L + h->has_next) * g.N * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(a.ub + g.N, u, nall, hipMemcpyHostToDevice, h->stream));
+    if (g.model == MODEL_IC) {
+        if (!w) return fail(h, MMC_ERR_INVALID_ARG, "mmc_debug_apply_K: this model needs w");
+        HIPCHK(h, hipMemcpyAsync(a.wb + g.N, w, nall, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, mmc_launch_dual(g, a, 0, h->L, MODE_RAW, false, h->stream));
+    if (out_p) HIPCHK(h, hipMemcpyAsync(out_p, a.p, (size_t)h->L * g.n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = download_dual(h, out_g1, out_g2))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = zero_duals(h))) return rc;
+    if ((rc = restore_xbar(h))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MMC_OK;
+}
+
+extern "C" int mmc_debug_apply_KT(mmc_handle *h, const float *p, const float *g1, const float *g2,
+                                  const float *ghost_g1t, const float *ghost_g2t,
+                                  float *out_u, float *out_w) {
+    REQUIRE_HANDLE(h);
+    if (!h->inited) return fail(h, MMC_ERR_STATE, "No initialization found, run mmc_init first.");
+    if (!p || !g1) return fail(h, MMC_ERR_INVALID_ARG, "mmc_debug_apply_KT: null input");
+    int rc = use_device(h); if (rc) return rc;
+    const Geom &g = h->g;
+    Arrays &a = h->a;
+    const size_t M = (size_t)h->L * g.N, B = M * sizeof(float), o = (size_t)g.N;
+    if ((rc = zero_duals(h))) return rc;
+    HIPCHK(h, hipMemcpyAsync(a.p, p, (size_t)h->L * g.n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(a.g1t + o, g1, B, hipMemcpyHostToDevice, h->stream));
+    if (g.model == MODEL_ADD) {
+        if (!g2) return fail(h, MMC_ERR_INVALID_ARG, "mmc_debug_apply_KT: null g2");
+        HIPCHK(h, hipMemcpyAsync(a.g1x + o, g2, B, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(a.g1y + o, g2 + M, B, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(a.g1x + o, g1 + M, B, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(a.g1y + o, g1 + 2 * M, B, hipMemcpyHostToDevice, h->stream));
+        if (g.model == MODEL_IC) {
+            if (!g2) return fail(h, MMC_ERR_INVALID_ARG, "mmc_debug_apply_KT: null g2");
+            HIPCHK(h, hipMemcpyAsync(a.g2t + o, g2, B, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(a.g2x + o, g2 + M, B, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(a.g2y + o, g2 + 2 * M, B, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    if (h->has_prev && ghost_g1t) HIPCHK(h, hipMemcpyAsync(a.g1t, ghost_g1t, o * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (h->has_prev && ghost_g2t && g.model == MODEL_IC)
+        HIPCHK(h, hipMemcpyAsync(a.g2t, ghost_g2t, o * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    // the sweeps keep temporal duals of masked rows at zero; K' relies on it
+    HIPCHK(h, mmc_launch_sanitize(g, a, h->stream));
+    HIPCHK(h, mmc_launch_primal(g, a, 0, h->L, MODE_RAW, false, h->stream));
+    if (out_u) HIPCHK(h, hipMemcpyAsync(out_u, a.ub + o, B, hipMemcpyDeviceToHost, h->stream));
+    if (out_w && g.model == MODEL_IC) HIPCHK(h, hipMemcpyAsync(out_w, a.wb + o, B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = zero_duals(h))) return rc;
+    if ((rc = restore_xbar(h))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MMC_OK;
+}
+
+extern "C" int mmc_debug_steps(mmc_handle *h, float *tau_u, float *tau_w,
+                               float *sigma_p, float *sigma_g1, float *sigma_g2) {
+    REQUIRE_HANDLE(h);
+    if (!h->inited) return fail(h, MMC_ERR_STATE, "No initialization found, run mmc_init first.");
+    int rc = use_device(h); if (rc) return rc;
+    const Geom &g = h->g;
+    Arrays &a = h->a;
+    const size_t B = (size_t)h->L * g.N * sizeof(float), o = (size_t)g.N;
+    HIPCHK(h, mmc_launch_primal(g, a, 0, h->L, MODE_STEPS, false, h->stream));
+    HIPCHK(h, mmc_launch_dual(g, a, 0, h->L, MODE_STEPS, false, h->stream));
+    if (tau_u) HIPCHK(h, hipMemcpyAsync(tau_u, a.ub + o, B, hipMemcpyDeviceToHost, h->stream));
+    if (tau_w && g.model == MODEL_IC) HIPCHK(h, hipMemcpyAsync(tau_w, a.wb + o, B, hipMemcpyDeviceToHost, h->stream));
+    if (sigma_p) HIPCHK(h, hipMemcpyAsync(sigma_p, a.p, (size_t)h->L * g.n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (sigma_g1) HIPCHK(h, hipMemcpyAsync(sigma_g1, a.g1t + o, B, hipMemcpyDeviceToHost, h->stream));
+    if (sigma_g2) HIPCHK(h, hipMemcpyAsync(sigma_g2, a.g2t + o, B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = zero_duals(h))) return rc;
+    if ((rc = restore_xbar(h))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MMC_OK;
+}

@@ -1,0 +1,57 @@
+// Internal interface between the C-ABI host code (mmc_capi.cpp) and the
+// gfx950 kernels (mmc_kernels.hip).  Not installed; include/mmc_hip.h is the
+// public header.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+enum { MODEL_IC = 0, MODEL_K1 = 1, MODEL_ADD = 2 };
+enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3 };
+
+// One workgroup of 256 threads owns a TILE_R x TILE_C pixel tile of one frame.
+// Rows are the contiguous axis (column-major frames), so one 64-lane wave
+// covers 64 consecutive rows of a column.
+enum { TILE_R = 64, TILE_C = 16, MMC_THREADS = 256 };
+enum { MMC_MAX_CK = 24 };      // max side of the composite (sampling * blur) kernel
+enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
+enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device
+
+struct Geom {
+    int Ny, Nx, N;             // high-resolution frame
+    int ny, nx, n;             // low-resolution frame
+    int f;                     // zoom factor
+    int L;                     // local frames
+    int frame_begin, nc_global;
+    int dir;                   // mmc_flow_direction
+    int model;                 // MODEL_*
+    int CH, CW, oy, ox;        // composite kernel size; first tap sits at f*R+oy, f*C+ox
+    int tiles_r, tiles_c, ntiles;
+    float alpha, kappa, inv_h;
+    float radius1, radius2;    // projection radii of the g1 / g2 groups
+};
+
+// Every per-pixel array holds L+2 frames: slot 0 is the ghost of the previous
+// block's last frame, slots 1..L the local frames, slot L+1 the ghost of the
+// next block's first frame.
+struct Arrays {
+    float *u, *w;              // primal iterate
+    float *ub, *wb;            // xbar = 2 x+ - x
+    float *g1t, *g1x, *g1y;    // dual of K1 (temporal, d/dcol, d/drow)
+    float *g2t, *g2x, *g2y;    // dual of K2
+    float *vx, *vy;            // flow of pair t (frame t <-> t+1); NaN = masked
+    float *cW;                 // column abs-sum of the motion-coupling operator
+    float *p, *f;              // data-term dual and low-res data, L*n
+    float *cA;                 // column abs-sum of D*B, N
+    float *sigp;               // 1 / row abs-sum of D*B, n
+    float *cker;               // composite kernel, CH x CW column-major
+    int *bbox;                 // [(L+1) pair slots][ntiles][4] = rmin,rmax,cmin,cmax
+    double *sums;              // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]
+};
+
+// Launchers (all asynchronous on `s`; return hipGetLastError()).
+hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s);
+hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s);
+hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, hipStream_t s);
+hipError_t mmc_launch_sanitize(const Geom &g, const Arrays &a, hipStream_t s);
+hipError_t mmc_launch_fold_occ(const Geom &g, float *vx, const uint8_t *occ, size_t count, hipStream_t s);
+hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s);

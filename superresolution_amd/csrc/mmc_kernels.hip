@@ -1,0 +1,605 @@
+// gfx950 kernels of the Multiframe Motion Coupling PDHG solve.
+//
+// The saddle-point problem is the one MultiframeMotionCoupling.m:346-574
+// (init_u_prost) assembles from sparse matrices; here every operator is
+// matrix-free:
+//   W   motion coupling   helpers/constructWarpFF.m, constructWarpFB.m
+//   A   blur + sampling   helpers/samplingOperator.m, helpers/RepConvMtx.m
+//   G   forward differences (spmat_gradient2d)
+// One PDHG iteration is two sweeps over HBM:
+//   primal sweep  x+ = prox_G(x - T K'y),  xbar = 2x+ - x
+//   dual sweep    y+ = prox_F*(y + S K xbar)
+// The adjoint of the bilinear warp is a scatter.  It is evaluated per target
+// tile: a workgroup walks the box of source pixels whose taps can land in its
+// tile (precomputed from the flow) and accumulates them in LDS, so no global
+// atomics are issued in the iteration.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include "mmc_internal.h"
+
+#define FR(ptr, t) ((ptr) + (size_t)((t) + 1) * (size_t)g.N)
+
+// --------------------------------------------------------------------------
+// small device helpers
+// --------------------------------------------------------------------------
+
+__device__ __forceinline__ bool pair_exists(const Geom &g, int q) {
+    int gq = g.frame_begin + q;
+    return q >= -1 && q <= g.L - 1 && gq >= 0 && gq <= g.nc_global - 2;
+}
+
+// true: row block q is  W_q x_{q+1} - x_q  ('I-F', constructWarpFF.m:40-48)
+// false:               W_q x_q - x_{q+1}  ('F-I', constructWarpFF.m:49-57)
+__device__ __forceinline__ bool pair_is_IF(const Geom &g, int q) {
+    if (g.dir == 1) return true;
+    if (g.dir == 0) return false;
+    return ((g.frame_begin + q) & 1) == 0;   // constructWarpFB.m:36, 1-based odd
+}
+
+struct Taps {
+    int i00, i10, i01, i11;      // in-frame linear indices of the four taps
+    int r0, r1, c0, c1;
+    float w00, w10, w01, w11;
+    bool valid;
+};
+
+// Bilinear taps of the sample position (r + vy, c + vx).  A position outside
+// the closed pixel domain (or NaN) masks the row.  Float32 arithmetic in this
+// exact order; the CPU oracle repeats it to reach the same floor() decisions.
+__device__ __forceinline__ Taps make_taps(const Geom &g, int r, int c, float vx, float vy) {
+    Taps t;
+    float y = (float)r + vy;
+    float x = (float)c + vx;
+    t.valid = (y >= 0.f) && (y <= (float)(g.Ny - 1)) && (x >= 0.f) && (x <= (float)(g.Nx - 1));
+    if (!t.valid) { y = 0.f; x = 0.f; }
+    float y0 = floorf(y), x0 = floorf(x);
+    float a = y - y0, b = x - x0;
+    t.r0 = (int)y0;
+    t.c0 = (int)x0;
+    t.r1 = min(t.r0 + 1, g.Ny - 1);
+    t.c1 = min(t.c0 + 1, g.Nx - 1);
+    float na = 1.f - a, nb = 1.f - b;
+    t.w00 = na * nb;
+    t.w10 = a * nb;
+    t.w01 = na * b;
+    t.w11 = a * b;
+    t.i00 = t.r0 + g.Ny * t.c0;
+    t.i10 = t.r1 + g.Ny * t.c0;
+    t.i01 = t.r0 + g.Ny * t.c1;
+    t.i11 = t.r1 + g.Ny * t.c1;
+    return t;
+}
+
+__device__ __forceinline__ float sample(const Taps &t, const float *img) {
+    return t.w00 * img[t.i00] + t.w10 * img[t.i10] + t.w01 * img[t.i01] + t.w11 * img[t.i11];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Sum NV per-thread values over the workgroup and add them to the slotted
+// double accumulators sums[first + i][slot].
+template <int NV>
+__device__ __forceinline__ void block_accumulate(float (&v)[NV], double *sums, int first) {
+    __shared__ float red[NV][MMC_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = wave_sum(v[i]);
+        if (lane == 0) red[i][wid] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < MMC_THREADS / 64; ++k) s += red[threadIdx.x][k];
+        int slot = (blockIdx.x + blockIdx.y * 7) & (MMC_SUM_SLOTS - 1);
+        atomicAdd(&sums[(size_t)(first + threadIdx.x) * MMC_SUM_SLOTS + slot], (double)s);
+    }
+}
+
+// (A' p)(r,c): gather form of the adjoint of D*B with the replicate border of
+// helpers/RepConvMtx.m:23-32 folded in: a border pixel also collects the
+// weights of the virtual rows / columns that clamp onto it.
+__device__ __forceinline__ float gather_ATp(const Geom &g, const float *__restrict__ cker,
+                                            const float *__restrict__ p, int r, int c) {
+    int rlo = r, rhi = r, clo = c, chi = c;
+    if (r == 0) rlo = min(g.oy, 0);
+    if (r == g.Ny - 1) rhi = max(g.Ny - 1, g.f * (g.ny - 1) + g.oy + g.CH - 1);
+    if (c == 0) clo = min(g.ox, 0);
+    if (c == g.Nx - 1) chi = max(g.Nx - 1, g.f * (g.nx - 1) + g.ox + g.CW - 1);
+    float acc = 0.f;
+    for (int cv = clo; cv <= chi; ++cv) {
+        int numc = cv - g.ox - g.CW + 1;
+        int Clo = numc > 0 ? (numc + g.f - 1) / g.f : 0;
+        int Chi = min((cv - g.ox) / g.f, g.nx - 1);
+        for (int C = Clo; C <= Chi; ++C) {
+            int nn = cv - g.f * C - g.ox;
+            for (int rv = rlo; rv <= rhi; ++rv) {
+                int numr = rv - g.oy - g.CH + 1;
+                int Rlo = numr > 0 ? (numr + g.f - 1) / g.f : 0;
+                int Rhi = min((rv - g.oy) / g.f, g.ny - 1);
+                for (int R = Rlo; R <= Rhi; ++R) {
+                    int mm = rv - g.f * R - g.oy;
+                    acc += cker[mm + g.CH * nn] * p[R + g.ny * C];
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+// (G' (gx,gy))(r,c) for forward differences with a zero last column / row.
+__device__ __forceinline__ float grad_adj(const Geom &g, const float *__restrict__ gx,
+                                          const float *__restrict__ gy, int r, int c, int j) {
+    float d = 0.f;
+    if (c > 0) d += gx[j - g.Ny];
+    if (c < g.Nx - 1) d -= gx[j];
+    if (r > 0) d += gy[j - 1];
+    if (r < g.Ny - 1) d -= gy[j];
+    return d;
+}
+
+// --------------------------------------------------------------------------
+// primal sweep
+// --------------------------------------------------------------------------
+// MODE_UPDATE: u,w <- prox_G(x - T K'y); ub,wb <- 2x+ - x
+// MODE_RAW   : ub,wb <- K'y           (test hook)
+// MODE_STEPS : ub,wb <- tau_u, tau_w  (test hook)
+template <int MODEL, int MODE, bool REDUCE>
+__global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0) {
+    __shared__ float acc1[TILE_R * TILE_C];
+    __shared__ float acc2[TILE_R * TILE_C];
+    const int t = t0 + blockIdx.y;
+    const int tile = blockIdx.x;
+    const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+    const int r0 = tr * TILE_R, c0 = tc * TILE_C;
+    const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
+
+    for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) {
+        acc1[k] = 0.f;
+        if (MODEL == MODEL_IC) acc2[k] = 0.f;
+    }
+    __syncthreads();
+
+    // --- scatter part of W': pairs whose warp samples THIS frame -----------
+    if (MODE != MODE_STEPS) {
+        for (int which = 0; which < 2; ++which) {
+            const int q = which == 0 ? t - 1 : t;
+            if (!pair_exists(g, q)) continue;
+            const bool isIF = pair_is_IF(g, q);
+            if ((which == 0) != isIF) continue;   // q=t-1 warps into t iff I-F; q=t iff F-I
+            const int *bb = a.bbox + ((size_t)(q + 1) * g.ntiles + tile) * 4;
+            const int rmin = bb[0], rmax = bb[1], cmin = bb[2], cmax = bb[3];
+            if (rmax < rmin || cmax < cmin) continue;
+            const int nr = rmax - rmin + 1, total = nr * (cmax - cmin + 1);
+            const float *vx = FR(a.vx, q), *vy = FR(a.vy, q);
+            const float *s1p = FR(a.g1t, q), *s2p = FR(a.g2t, q);
+            for (int idx = threadIdx.x; idx < total; idx += MMC_THREADS) {
+                const int r = rmin + idx % nr, c = cmin + idx / nr;
+                const int j = r + g.Ny * c;
+                Taps tp = make_taps(g, r, c, vx[j], vy[j]);
+                if (!tp.valid) continue;
+                const float s1 = s1p[j];
+                float s2 = 0.f;
+                if (MODEL == MODEL_IC) s2 = kap * s2p[j] - s1;
+                const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
+                const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
+                const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
+                if (ra0 && cb0) { atomicAdd(&acc1[a0 + TILE_R * b0], tp.w00 * s1); if (MODEL == MODEL_IC) atomicAdd(&acc2[a0 + TILE_R * b0], tp.w00 * s2); }
+                if (ra1 && cb0) { atomicAdd(&acc1[a1 + TILE_R * b0], tp.w10 * s1); if (MODEL == MODEL_IC) atomicAdd(&acc2[a1 + TILE_R * b0], tp.w10 * s2); }
+                if (ra0 && cb1) { atomicAdd(&acc1[a0 + TILE_R * b1], tp.w01 * s1); if (MODEL == MODEL_IC) atomicAdd(&acc2[a0 + TILE_R * b1], tp.w01 * s2); }
+                if (ra1 && cb1) { atomicAdd(&acc1[a1 + TILE_R * b1], tp.w11 * s1); if (MODEL == MODEL_IC) atomicAdd(&acc2[a1 + TILE_R * b1], tp.w11 * s2); }
+            }
+        }
+        __syncthreads();
+    }
+
+    // --- identity part of W': pairs whose -Id block sits on THIS frame ------
+    const bool idA = pair_exists(g, t) && pair_is_IF(g, t);              // -Id of pair t
+    const bool idB = pair_exists(g, t - 1) && !pair_is_IF(g, t - 1);     // -Id of pair t-1
+    const float *idA1 = FR(a.g1t, t), *idA2 = FR(a.g2t, t);
+    const float *idB1 = FR(a.g1t, t - 1), *idB2 = FR(a.g2t, t - 1);
+
+    float *u = FR(a.u, t), *w = FR(a.w, t), *ub = FR(a.ub, t), *wb = FR(a.wb, t);
+    const float *g1x = FR(a.g1x, t), *g1y = FR(a.g1y, t), *g2x = FR(a.g2x, t), *g2y = FR(a.g2y, t);
+    const float *cW = FR(a.cW, t);
+    const float *p = a.p + (size_t)t * g.n;
+    float part[2] = {0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < TILE_R * TILE_C / MMC_THREADS; ++s) {
+        const int k = threadIdx.x + MMC_THREADS * s;
+        const int r = r0 + (k % TILE_R), c = c0 + (k / TILE_R);
+        if (r >= g.Ny || c >= g.Nx) continue;
+        const int j = r + g.Ny * c;
+        const float cgrad = (float)((c < g.Nx - 1) + (c > 0) + (r < g.Ny - 1) + (r > 0));
+        const float cw = cW[j] * g.inv_h;
+        float tau_u, tau_w = 0.f;
+        if (MODEL == MODEL_IC) {
+            tau_u = 1.f / (a.cA[j] + cw + kap * cgrad);
+            tau_w = 1.f / ((1.f + kap) * (cw + cgrad));
+        } else {
+            tau_u = 1.f / (a.cA[j] + cw + cgrad);
+        }
+        if (MODE == MODE_STEPS) {
+            ub[j] = tau_u;
+            if (MODEL == MODEL_IC) wb[j] = tau_w;
+            continue;
+        }
+        float Wt1 = acc1[k], Wt2 = (MODEL == MODEL_IC) ? acc2[k] : 0.f;
+        if (idA) {
+            const float s1 = idA1[j];
+            Wt1 -= s1;
+            if (MODEL == MODEL_IC) Wt2 -= kap * idA2[j] - s1;
+        }
+        if (idB) {
+            const float s1 = idB1[j];
+            Wt1 -= s1;
+            if (MODEL == MODEL_IC) Wt2 -= kap * idB2[j] - s1;
+        }
+        const float div1 = grad_adj(g, g1x, g1y, r, c, j);
+        const float ATp = gather_ATp(g, a.cker, p, r, c);
+        const float KTu = ATp + g.inv_h * Wt1 + kap * div1;
+        float KTw = 0.f;
+        if (MODEL == MODEL_IC) {
+            const float div2 = grad_adj(g, g2x, g2y, r, c, j);
+            KTw = g.inv_h * Wt2 - kap * div1 + div2;
+        }
+        if (MODE == MODE_RAW) {
+            ub[j] = KTu;
+            if (MODEL == MODEL_IC) wb[j] = KTw;
+            continue;
+        }
+        const float uo = u[j];
+        const float un = fminf(fmaxf(uo - tau_u * KTu, 0.f), 1.f);   // G = ind[0,1], :495
+        u[j] = un;
+        ub[j] = 2.f * un - uo;
+        if (REDUCE) { part[0] += (un - uo) * (un - uo); part[1] += un * un; }
+        if (MODEL == MODEL_IC) {
+            const float wo = w[j];
+            const float wn = wo - tau_w * KTw;
+            w[j] = wn;
+            wb[j] = 2.f * wn - wo;
+            if (REDUCE) { part[0] += (wn - wo) * (wn - wo); part[1] += wn * wn; }
+        }
+    }
+    if (REDUCE) block_accumulate<2>(part, a.sums, 0);
+}
+
+// --------------------------------------------------------------------------
+// dual sweep, regulariser part (g1, g2)
+// --------------------------------------------------------------------------
+// MODE_UPDATE: g <- proj(g + S K xbar)
+// MODE_RAW   : g <- K xbar                     (test hook)
+// MODE_STEPS : g?t <- sigma of the group       (test hook)
+// MODE_ENERGY: sums[4] += alpha*sum ||(K x)_j|| (reads ub/wb pointers as given)
+template <int MODEL, int MODE, bool REDUCE>
+__global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) {
+    const int t = t0 + blockIdx.y;
+    const int tile = blockIdx.x;
+    const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+    const int r0 = tr * TILE_R, c0 = tc * TILE_C;
+    const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
+    const bool pex = pair_exists(g, t);
+    const bool isIF = pair_is_IF(g, t);
+    const float *ub = FR(a.ub, t), *wb = FR(a.wb, t);
+    const float *ubW = FR(a.ub, isIF ? t + 1 : t), *wbW = FR(a.wb, isIF ? t + 1 : t);   // warped frame
+    const float *ubI = FR(a.ub, isIF ? t : t + 1), *wbI = FR(a.wb, isIF ? t : t + 1);   // identity frame
+    const float *vx = FR(a.vx, t), *vy = FR(a.vy, t);
+    float *g1t = FR(a.g1t, t), *g1x = FR(a.g1x, t), *g1y = FR(a.g1y, t);
+    float *g2t = FR(a.g2t, t), *g2x = FR(a.g2x, t), *g2y = FR(a.g2y, t);
+    float part[2] = {0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < TILE_R * TILE_C / MMC_THREADS; ++s) {
+        const int k = threadIdx.x + MMC_THREADS * s;
+        const int r = r0 + (k % TILE_R), c = c0 + (k / TILE_R);
+        if (r >= g.Ny || c >= g.Nx) continue;
+        const int j = r + g.Ny * c;
+        const bool hasx = c < g.Nx - 1, hasy = r < g.Ny - 1;
+
+        const float uc = ub[j];
+        const float ux = hasx ? ub[j + g.Ny] : uc;
+        const float uy = hasy ? ub[j + 1] : uc;
+        float wc = 0.f, wx = 0.f, wy = 0.f;
+        if (MODEL == MODEL_IC) {
+            wc = wb[j];
+            wx = hasx ? wb[j + g.Ny] : wc;
+            wy = hasy ? wb[j + 1] : wc;
+        }
+        // temporal rows: W xbar for this pair
+        bool valid = false;
+        float tu = 0.f, tw = 0.f;
+        if (pex) {
+            Taps tp = make_taps(g, r, c, vx[j], vy[j]);
+            valid = tp.valid;
+            if (valid) {
+                tu = sample(tp, ubW) - ubI[j];
+                if (MODEL == MODEL_IC) tw = sample(tp, wbW) - wbI[j];
+            }
+        }
+        float k1t, k1x, k1y, k2t = 0.f, k2x = 0.f, k2y = 0.f;
+        float rs1, rs2 = 0.f;
+        if (MODEL == MODEL_IC) {
+            // K1 (u - w), K1 = [W/h ; kappa G]  (:490-491);  K2 w, K2 = [kappa W/h ; G]  (:492)
+            k1t = (tu - tw) * g.inv_h;
+            k1x = kap * ((ux - wx) - (uc - wc));
+            k1y = kap * ((uy - wy) - (uc - wc));
+            k2t = kap * tw * g.inv_h;
+            k2x = wx - wc;
+            k2y = wy - wc;
+            rs1 = fmaxf(valid ? 4.f * g.inv_h : 0.f, fmaxf(hasx ? 4.f * kap : 0.f, hasy ? 4.f * kap : 0.f));
+            rs2 = fmaxf(valid ? 2.f * kap * g.inv_h : 0.f, fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f));
+        } else {
+            k1t = tu * g.inv_h;
+            k1x = ux - uc;
+            k1y = uy - uc;
+            if (MODEL == MODEL_K1) {
+                rs1 = fmaxf(valid ? 2.f * g.inv_h : 0.f, fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f));
+            } else {   // additive: temporal row alone (rs1), spatial pair (rs2)
+                rs1 = valid ? 2.f * g.inv_h : 0.f;
+                rs2 = fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f);
+            }
+        }
+        const float sg1 = rs1 > 0.f ? 1.f / rs1 : 1.f;
+        const float sg2 = rs2 > 0.f ? 1.f / rs2 : 1.f;
+
+        if (MODE == MODE_RAW) {
+            g1t[j] = k1t; g1x[j] = k1x; g1y[j] = k1y;
+            if (MODEL == MODEL_IC) { g2t[j] = k2t; g2x[j] = k2x; g2y[j] = k2y; }
+            continue;
+        }
+        if (MODE == MODE_STEPS) {
+            g1t[j] = sg1;
+            g2t[j] = sg2;
+            continue;
+        }
+        if (MODE == MODE_ENERGY) {
+            if (MODEL == MODEL_IC) {
+                part[0] += g.radius1 * sqrtf(k1t * k1t + k1x * k1x + k1y * k1y) +
+                           g.radius2 * sqrtf(k2t * k2t + k2x * k2x + k2y * k2y);
+            } else if (MODEL == MODEL_K1) {
+                part[0] += g.radius1 * sqrtf(k1t * k1t + k1x * k1x + k1y * k1y);
+            } else {
+                part[0] += g.radius1 * fabsf(k1t) + g.radius2 * sqrtf(k1x * k1x + k1y * k1y);
+            }
+            continue;
+        }
+        // MODE_UPDATE
+        const float o1t = g1t[j], o1x = g1x[j], o1y = g1y[j];
+        float n1t, n1x, n1y;
+        if (MODEL == MODEL_ADD) {
+            // |g1| <= alpha (:532) on the temporal row, ||(gx,gy)|| <= alpha (:533)
+            n1t = valid ? fminf(fmaxf(o1t + sg1 * k1t, -g.radius1), g.radius1) : 0.f;
+            n1x = o1x + sg2 * k1x;
+            n1y = o1y + sg2 * k1y;
+            const float nrm = sqrtf(n1x * n1x + n1y * n1y);
+            if (nrm > g.radius2) { const float sc = g.radius2 / nrm; n1x *= sc; n1y *= sc; }
+        } else {
+            // ||(gt,gx,gy)||_2 <= radius (:497, :513)
+            n1t = valid ? o1t + sg1 * k1t : 0.f;
+            n1x = o1x + sg1 * k1x;
+            n1y = o1y + sg1 * k1y;
+            const float nrm = sqrtf(n1t * n1t + n1x * n1x + n1y * n1y);
+            if (nrm > g.radius1) { const float sc = g.radius1 / nrm; n1t *= sc; n1x *= sc; n1y *= sc; }
+        }
+        g1t[j] = n1t; g1x[j] = n1x; g1y[j] = n1y;
+        if (REDUCE) {
+            part[0] += (n1t - o1t) * (n1t - o1t) + (n1x - o1x) * (n1x - o1x) + (n1y - o1y) * (n1y - o1y);
+            part[1] += n1t * n1t + n1x * n1x + n1y * n1y;
+        }
+        if (MODEL == MODEL_IC) {
+            const float o2t = g2t[j], o2x = g2x[j], o2y = g2y[j];
+            float n2t = valid ? o2t + sg2 * k2t : 0.f;
+            float n2x = o2x + sg2 * k2x;
+            float n2y = o2y + sg2 * k2y;
+            const float nrm = sqrtf(n2t * n2t + n2x * n2x + n2y * n2y);
+            if (nrm > g.radius2) { const float sc = g.radius2 / nrm; n2t *= sc; n2x *= sc; n2y *= sc; }
+            g2t[j] = n2t; g2x[j] = n2x; g2y[j] = n2y;
+            if (REDUCE) {
+                part[0] += (n2t - o2t) * (n2t - o2t) + (n2x - o2x) * (n2x - o2x) + (n2y - o2y) * (n2y - o2y);
+                part[1] += n2t * n2t + n2x * n2x + n2y * n2y;
+            }
+        }
+    }
+    if (MODE == MODE_ENERGY) { float e[1] = {part[0]}; block_accumulate<1>(e, a.sums, 4); }
+    else if (REDUCE) block_accumulate<2>(part, a.sums, 2);
+}
+
+// --------------------------------------------------------------------------
+// dual sweep, data part (p):  p <- clamp(p + s (A ub - f), -1, 1)   (:496)
+// --------------------------------------------------------------------------
+template <int MODE, bool REDUCE>
+__global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0, int nframes) {
+    const size_t idx = (size_t)blockIdx.x * MMC_THREADS + threadIdx.x;
+    float part[2] = {0.f, 0.f};
+    if (idx < (size_t)g.n * nframes) {
+        const int t = t0 + (int)(idx / g.n);
+        const int i = (int)(idx % g.n);
+        const int R = i % g.ny, C = i / g.ny;
+        const float *ub = FR(a.ub, t);
+        float acc = 0.f;
+        for (int nn = 0; nn < g.CW; ++nn) {
+            const int cc = min(max(g.f * C + g.ox + nn, 0), g.Nx - 1);
+            const float *col = ub + (size_t)g.Ny * cc;
+            for (int mm = 0; mm < g.CH; ++mm) {
+                const int rr = min(max(g.f * R + g.oy + mm, 0), g.Ny - 1);
+                acc += a.cker[mm + g.CH * nn] * col[rr];
+            }
+        }
+        const size_t o = (size_t)t * g.n + i;
+        const float sg = a.sigp[i];
+        if (MODE == MODE_RAW) {
+            a.p[o] = acc;
+        } else if (MODE == MODE_STEPS) {
+            a.p[o] = sg;
+        } else if (MODE == MODE_ENERGY) {
+            part[0] = fabsf(acc - a.f[o]);
+        } else {
+            const float po = a.p[o];
+            const float pn = fminf(fmaxf(po + sg * (acc - a.f[o]), -1.f), 1.f);
+            a.p[o] = pn;
+            if (REDUCE) { part[0] = (pn - po) * (pn - po); part[1] = pn * pn; }
+        }
+    }
+    if (MODE == MODE_ENERGY) { float e[1] = {part[0]}; block_accumulate<1>(e, a.sums, 5); }
+    else if (REDUCE) block_accumulate<2>(part, a.sums, 2);
+}
+
+// --------------------------------------------------------------------------
+// one-off kernels
+// --------------------------------------------------------------------------
+
+// Column abs-sums of the motion-coupling operator and, per target tile, the
+// bounding box of the source pixels whose taps land in it.
+__global__ __launch_bounds__(MMC_THREADS) void k_init_warp(Geom g, Arrays a) {
+    const int q = (int)blockIdx.y - 1;
+    if (!pair_exists(g, q)) return;
+    const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    const int r = j % g.Ny, c = j / g.Ny;
+    Taps tp = make_taps(g, r, c, FR(a.vx, q)[j], FR(a.vy, q)[j]);
+    if (!tp.valid) return;
+    const bool isIF = pair_is_IF(g, q);
+    const int wf = isIF ? q + 1 : q, idf = isIF ? q : q + 1;
+    if (wf >= 0 && wf < g.L) {
+        float *cW = FR(a.cW, wf);
+        atomicAdd(&cW[tp.i00], tp.w00);
+        atomicAdd(&cW[tp.i10], tp.w10);
+        atomicAdd(&cW[tp.i01], tp.w01);
+        atomicAdd(&cW[tp.i11], tp.w11);
+        int *bb = a.bbox + (size_t)(q + 1) * g.ntiles * 4;
+        const int tr0 = tp.r0 / TILE_R, tr1 = tp.r1 / TILE_R, tc0 = tp.c0 / TILE_C, tc1 = tp.c1 / TILE_C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ttr = (k & 1) ? tr1 : tr0, ttc = (k & 2) ? tc1 : tc0;
+            if (k == 1 && tr1 == tr0) continue;
+            if (k == 2 && tc1 == tc0) continue;
+            if (k == 3 && (tr1 == tr0 || tc1 == tc0)) continue;
+            int *b = bb + (size_t)(ttr + g.tiles_r * ttc) * 4;
+            atomicMin(&b[0], r); atomicMax(&b[1], r);
+            atomicMin(&b[2], c); atomicMax(&b[3], c);
+        }
+    }
+    if (idf >= 0 && idf < g.L) atomicAdd(&FR(a.cW, idf)[j], 1.f);
+}
+
+// Temporal duals of masked rows are identically zero; enforce it after a flow
+// swap so that the primal sweep may subtract them without re-reading the mask.
+__global__ __launch_bounds__(MMC_THREADS) void k_sanitize(Geom g, Arrays a) {
+    const int q = blockIdx.y;
+    const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    bool valid = false;
+    if (pair_exists(g, q)) {
+        const int r = j % g.Ny, c = j / g.Ny;
+        valid = make_taps(g, r, c, FR(a.vx, q)[j], FR(a.vy, q)[j]).valid;
+    }
+    if (!valid) { FR(a.g1t, q)[j] = 0.f; FR(a.g2t, q)[j] = 0.f; }
+}
+
+__global__ __launch_bounds__(MMC_THREADS) void k_fold_occ(float *vx, const uint8_t *occ, size_t count) {
+    const size_t i = (size_t)blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (i < count && occ[i]) vx[i] = __builtin_nanf("");
+}
+
+// sums[6] += sum |W ub| over owned pairs, sums[7] += sum |G ub| over local
+// frames  (MultiframeMotionCoupling.m:431-437).
+__global__ __launch_bounds__(MMC_THREADS) void k_h_partials(Geom g, Arrays a) {
+    const int t = blockIdx.y;
+    const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    float part[2] = {0.f, 0.f};
+    if (j < g.N) {
+        const int r = j % g.Ny, c = j / g.Ny;
+        const float *ub = FR(a.ub, t);
+        const float uc = ub[j];
+        if (c < g.Nx - 1) part[1] += fabsf(ub[j + g.Ny] - uc);
+        if (r < g.Ny - 1) part[1] += fabsf(ub[j + 1] - uc);
+        if (pair_exists(g, t)) {
+            Taps tp = make_taps(g, r, c, FR(a.vx, t)[j], FR(a.vy, t)[j]);
+            if (tp.valid) {
+                const bool isIF = pair_is_IF(g, t);
+                const float *W = FR(a.ub, isIF ? t + 1 : t), *I = FR(a.ub, isIF ? t : t + 1);
+                part[0] += fabsf(sample(tp, W) - I[j]);
+            }
+        }
+    }
+    block_accumulate<2>(part, a.sums, 6);
+}
+
+// --------------------------------------------------------------------------
+// launchers
+// --------------------------------------------------------------------------
+
+template <int MODEL>
+static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+    dim3 grid(g.ntiles, nf), block(MMC_THREADS);
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal<MODEL, MODE_RAW, false>), grid, block, 0, s, g, a, t0);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal<MODEL, MODE_STEPS, false>), grid, block, 0, s, g, a, t0);
+    else if (reduce) hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, true>), grid, block, 0, s, g, a, t0);
+    else hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
+}
+
+hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s) {
+    if (t1 <= t0) return hipSuccess;
+    if (g.model == MODEL_IC) launch_primal_m<MODEL_IC>(g, a, t0, t1 - t0, mode, reduce, s);
+    else if (g.model == MODEL_K1) launch_primal_m<MODEL_K1>(g, a, t0, t1 - t0, mode, reduce, s);
+    else launch_primal_m<MODEL_ADD>(g, a, t0, t1 - t0, mode, reduce, s);
+    return hipGetLastError();
+}
+
+template <int MODEL>
+static void launch_dual_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+    dim3 grid(g.ntiles, nf), block(MMC_THREADS);
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual<MODEL, MODE_RAW, false>), grid, block, 0, s, g, a, t0);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual<MODEL, MODE_STEPS, false>), grid, block, 0, s, g, a, t0);
+    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual<MODEL, MODE_ENERGY, false>), grid, block, 0, s, g, a, t0);
+    else if (reduce) hipLaunchKernelGGL((k_dual<MODEL, MODE_UPDATE, true>), grid, block, 0, s, g, a, t0);
+    else hipLaunchKernelGGL((k_dual<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
+}
+
+hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s) {
+    if (t1 <= t0) return hipSuccess;
+    const int nf = t1 - t0;
+    if (g.model == MODEL_IC) launch_dual_m<MODEL_IC>(g, a, t0, nf, mode, reduce, s);
+    else if (g.model == MODEL_K1) launch_dual_m<MODEL_K1>(g, a, t0, nf, mode, reduce, s);
+    else launch_dual_m<MODEL_ADD>(g, a, t0, nf, mode, reduce, s);
+    const size_t total = (size_t)g.n * nf;
+    dim3 gridp((unsigned)((total + MMC_THREADS - 1) / MMC_THREADS)), block(MMC_THREADS);
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual_p<MODE_RAW, false>), gridp, block, 0, s, g, a, t0, nf);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual_p<MODE_STEPS, false>), gridp, block, 0, s, g, a, t0, nf);
+    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual_p<MODE_ENERGY, false>), gridp, block, 0, s, g, a, t0, nf);
+    else if (reduce) hipLaunchKernelGGL((k_dual_p<MODE_UPDATE, true>), gridp, block, 0, s, g, a, t0, nf);
+    else hipLaunchKernelGGL((k_dual_p<MODE_UPDATE, false>), gridp, block, 0, s, g, a, t0, nf);
+    return hipGetLastError();
+}
+
+hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, hipStream_t s) {
+    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS, g.L + 1), block(MMC_THREADS);
+    hipLaunchKernelGGL(k_init_warp, grid, block, 0, s, g, a);
+    return hipGetLastError();
+}
+
+hipError_t mmc_launch_sanitize(const Geom &g, const Arrays &a, hipStream_t s) {
+    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS, g.L), block(MMC_THREADS);
+    hipLaunchKernelGGL(k_sanitize, grid, block, 0, s, g, a);
+    return hipGetLastError();
+}
+
+hipError_t mmc_launch_fold_occ(const Geom &g, float *vx, const uint8_t *occ, size_t count, hipStream_t s) {
+    (void)g;
+    if (count == 0) return hipSuccess;
+    dim3 grid((unsigned)((count + MMC_THREADS - 1) / MMC_THREADS)), block(MMC_THREADS);
+    hipLaunchKernelGGL(k_fold_occ, grid, block, 0, s, vx, occ, count);
+    return hipGetLastError();
+}
+
+hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s) {
+    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS, g.L), block(MMC_THREADS);
+    hipLaunchKernelGGL(k_h_partials, grid, block, 0, s, g, a);
+    return hipGetLastError();
+}

@@ -1,0 +1,237 @@
+"""FrameBlockSolver: numpy-facing wrapper of one libmmc_hip handle.
+
+One instance owns the device state of a contiguous block of frames.  For a
+whole sequence on one GPU the block is [0, nc); a sharded sequence uses one
+block per rank (see sharding.py).  Arrays follow the reference's MATLAB layout:
+frames are (rows, cols, frame) and flows (Ny, Nx, pairs, 2) with component 0
+the displacement along columns (helpers/constructWarpFF.m:5).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import MMCError, as_f32, fptr
+
+_DIRECTIONS = {"forward": _capi.FLOW_FORWARD, "backward": _capi.FLOW_BACKWARD,
+               "forward-backward": _capi.FLOW_FORWARD_BACKWARD}
+_SAMPLINGS = {"average": _capi.SAMPLING_AVERAGE, "stride": _capi.SAMPLING_STRIDE}
+
+
+class FrameBlockSolver(object):
+    def __init__(self, ny, nx, factor, nc_global, frame_begin=0, frame_end=None,
+                 alpha=0.01, kappa=0.25, h=0.0, flow_direction="backward",
+                 sampling="average", device=0, stream=None):
+        self._lib = _capi.load_library()
+        self._h = C.c_void_p()
+        if flow_direction not in _DIRECTIONS:
+            raise ValueError("Invalid flow direction.")
+        if sampling not in _SAMPLINGS:
+            raise MMCError(-4, "interpMethod '%s' is not implemented by the HIP path "
+                               "(only 'average' and 'stride')" % sampling)
+        frame_end = nc_global if frame_end is None else frame_end
+        p = _capi.mmc_params()
+        p.size = C.sizeof(_capi.mmc_params)
+        p.version = _capi.MMC_ABI_VERSION
+        p.ny, p.nx, p.factor = int(ny), int(nx), int(factor)
+        p.nc_global, p.frame_begin, p.frame_end = int(nc_global), int(frame_begin), int(frame_end)
+        p.alpha, p.kappa, p.h = float(alpha), float(kappa), float(h)
+        p.flow_direction = _DIRECTIONS[flow_direction]
+        p.sampling = _SAMPLINGS[sampling]
+        p.device = int(device)
+        p.stream = stream
+        self.params = p
+        rc = self._lib.mmc_create(C.byref(p), C.byref(self._h))
+        if rc != 0:
+            raise MMCError(rc, self._lib.mmc_last_error(None).decode())
+        self.ny, self.nx, self.factor = int(ny), int(nx), int(factor)
+        self.Ny, self.Nx = self.ny * self.factor, self.nx * self.factor
+        self.L = int(frame_end) - int(frame_begin)
+        self.nc_global = int(nc_global)
+        self.frame_begin, self.frame_end = int(frame_begin), int(frame_end)
+        self.has_prev = frame_begin > 0
+        self.has_next = frame_end < nc_global
+        self.has_w = not (np.isnan(kappa) or kappa == 1)
+        self.additive = bool(np.isnan(kappa))
+        self._cb_keepalive = None
+
+    # -- plumbing ----------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise MMCError(rc, self._lib.mmc_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mmc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def num_flow_pairs(self):
+        return self._lib.mmc_num_flow_pairs(self._h)
+
+    @property
+    def num_state_frames(self):
+        return self._lib.mmc_num_state_frames(self._h)
+
+    # -- inputs ------------------------------------------------------------
+    def set_lowres(self, f):
+        f = as_f32(f)
+        if f.shape != (self.ny, self.nx, self.L):
+            raise ValueError("low-res block must be %s, got %s" % ((self.ny, self.nx, self.L), f.shape))
+        self._check(self._lib.mmc_set_lowres(self._h, fptr(f)))
+
+    def set_blur(self, k):
+        if k is None or np.size(k) == 0:
+            self._check(self._lib.mmc_set_blur(self._h, None, 0, 0))
+            return
+        k = as_f32(np.atleast_2d(k))
+        self._check(self._lib.mmc_set_blur(self._h, fptr(k), k.shape[0], k.shape[1]))
+
+    def set_flow(self, v, occ=None):
+        npairs = self.num_flow_pairs
+        if npairs == 0:
+            self._check(self._lib.mmc_set_flow(self._h, None, None))
+            return
+        v = as_f32(v).reshape((self.Ny, self.Nx, -1, 2), order="F")
+        if v.shape[2] != npairs:
+            raise ValueError("flow must hold %d pairs, got %d" % (npairs, v.shape[2]))
+        o = None
+        if occ is not None:
+            o = np.asfortranarray(np.asarray(occ).reshape((self.Ny, self.Nx, npairs), order="F") != 0,
+                                  dtype=np.uint8)
+        self._check(self._lib.mmc_set_flow(self._h, fptr(v),
+                                           None if o is None else o.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def set_state(self, u, w=None):
+        nf = self.num_state_frames
+        u = as_f32(u)
+        if u.shape != (self.Ny, self.Nx, nf):
+            raise ValueError("state must be %s, got %s" % ((self.Ny, self.Nx, nf), u.shape))
+        if self.has_w:
+            w = as_f32(u if w is None else w)
+            if w.shape != u.shape:
+                raise ValueError("w must have the shape of u")
+        else:
+            w = None
+        self._check(self._lib.mmc_set_state(self._h, fptr(u), fptr(w)))
+
+    def init(self):
+        self._check(self._lib.mmc_init(self._h))
+
+    # -- h -----------------------------------------------------------------
+    def h_partials(self):
+        out = (C.c_double * 2)()
+        self._check(self._lib.mmc_h_partials(self._h, out))
+        return float(out[0]), float(out[1])
+
+    @property
+    def h(self):
+        v = C.c_float()
+        self._check(self._lib.mmc_get_h(self._h, C.byref(v)))
+        return float(v.value)
+
+    @h.setter
+    def h(self, value):
+        self._check(self._lib.mmc_set_h(self._h, float(value)))
+
+    # -- solve -------------------------------------------------------------
+    def solve(self, max_iters, tol=0.0, check_every=0, callback=None):
+        st = _capi.mmc_stats()
+        if callback is not None:
+            def _cb(it, stp, _user):
+                s = stp.contents
+                return int(bool(callback(it, {"res_primal": s.res_primal, "res_dual": s.res_dual,
+                                              "seconds": s.solve_seconds})))
+            cb = _capi.PROGRESS_CB(_cb)
+        else:
+            cb = _capi.PROGRESS_CB()
+        self._cb_keepalive = cb
+        self._check(self._lib.mmc_solve(self._h, int(max_iters), float(tol), int(check_every),
+                                        C.byref(st), cb, None))
+        return {"iterations": st.iterations, "converged": bool(st.converged),
+                "res_primal": st.res_primal, "res_dual": st.res_dual, "seconds": st.solve_seconds}
+
+    def sweep_primal(self, t0, t1, reduce=False):
+        self._check(self._lib.mmc_sweep_primal(self._h, int(t0), int(t1), int(reduce)))
+
+    def sweep_dual(self, t0, t1, reduce=False):
+        self._check(self._lib.mmc_sweep_dual(self._h, int(t0), int(t1), int(reduce)))
+
+    def sums_reset(self):
+        self._check(self._lib.mmc_sums_reset(self._h))
+
+    def sums_read(self):
+        out = (C.c_double * _capi.MMC_NUM_SUMS)()
+        self._check(self._lib.mmc_sums_read(self._h, out))
+        return np.array(list(out), dtype=np.float64)
+
+    def halo_info(self):
+        hl = _capi.mmc_halo()
+        self._check(self._lib.mmc_halo_info(self._h, C.byref(hl)))
+        return hl
+
+    def sync(self):
+        self._check(self._lib.mmc_sync(self._h))
+
+    def energy(self):
+        v = C.c_double()
+        self._check(self._lib.mmc_energy(self._h, C.byref(v)))
+        return float(v.value)
+
+    # -- outputs -----------------------------------------------------------
+    def get_state(self):
+        u = np.empty((self.Ny, self.Nx, self.L), dtype=np.float32, order="F")
+        w = np.empty_like(u) if self.has_w else None
+        self._check(self._lib.mmc_get_state(self._h, fptr(u), fptr(w)))
+        return u, w
+
+    # -- test hooks --------------------------------------------------------
+    def debug_apply_K(self, u, w=None):
+        nf = self.num_state_frames
+        u = as_f32(u)
+        assert u.shape == (self.Ny, self.Nx, nf)
+        w = as_f32(w) if self.has_w else None
+        N, n, L = self.Ny * self.Nx, self.ny * self.nx, self.L
+        out_p = np.empty(n * L, np.float32)
+        if self.additive:
+            g1 = np.empty(N * L, np.float32)
+            g2 = np.empty(2 * N * L, np.float32)
+        else:
+            g1 = np.empty(3 * N * L, np.float32)
+            g2 = np.empty(3 * N * L, np.float32) if self.has_w else None
+        self._check(self._lib.mmc_debug_apply_K(self._h, fptr(u), fptr(w), fptr(out_p), fptr(g1), fptr(g2)))
+        return out_p, g1, g2
+
+    def debug_apply_KT(self, p, g1, g2=None, ghost_g1t=None, ghost_g2t=None):
+        N, L = self.Ny * self.Nx, self.L
+        p, g1 = as_f32(p).ravel(), as_f32(g1).ravel()
+        g2 = None if g2 is None else as_f32(g2).ravel()
+        gh1 = None if ghost_g1t is None else as_f32(ghost_g1t).ravel(order="F")
+        gh2 = None if ghost_g2t is None else as_f32(ghost_g2t).ravel(order="F")
+        out_u = np.empty(N * L, np.float32)
+        out_w = np.empty(N * L, np.float32) if self.has_w else None
+        self._check(self._lib.mmc_debug_apply_KT(self._h, fptr(p), fptr(g1), fptr(g2), fptr(gh1), fptr(gh2),
+                                                 fptr(out_u), fptr(out_w)))
+        return out_u, out_w
+
+    def debug_steps(self):
+        N, n, L = self.Ny * self.Nx, self.ny * self.nx, self.L
+        tu = np.empty(N * L, np.float32)
+        tw = np.empty(N * L, np.float32) if self.has_w else None
+        sp = np.empty(n * L, np.float32)
+        s1 = np.empty(N * L, np.float32)
+        s2 = np.empty(N * L, np.float32)
+        self._check(self._lib.mmc_debug_steps(self._h, fptr(tu), fptr(tw), fptr(sp), fptr(s1), fptr(s2)))
+        return tu, tw, sp, s1, s2

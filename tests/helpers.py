@@ -1,0 +1,47 @@
+"""Shared synthetic inputs for the tests (seeded, small)."""
+import numpy as np
+
+
+def smooth_field(rng, shape, scale, cells=4):
+    """Low-frequency random field: bilinear blow-up of a coarse random grid."""
+    Ny, Nx = shape
+    coarse = rng.normal(0.0, scale, (cells + 1, cells + 1))
+    yy = np.linspace(0, cells, Ny)
+    xx = np.linspace(0, cells, Nx)
+    y0 = np.clip(np.floor(yy).astype(int), 0, cells - 1)
+    x0 = np.clip(np.floor(xx).astype(int), 0, cells - 1)
+    a = (yy - y0)[:, None]
+    b = (xx - x0)[None, :]
+    return ((1 - a) * (1 - b) * coarse[np.ix_(y0, x0)] + a * (1 - b) * coarse[np.ix_(y0 + 1, x0)]
+            + (1 - a) * b * coarse[np.ix_(y0, x0 + 1)] + a * b * coarse[np.ix_(y0 + 1, x0 + 1)])
+
+
+def make_case(seed, ny, nx, nc, factor=4, flow="smooth", flow_scale=2.0, with_occ=False):
+    """Low-res frames in [0,1], flows (Ny,Nx,nc-1,2) and optional occlusion maps."""
+    rng = np.random.default_rng(seed)
+    Ny, Nx = factor * ny, factor * nx
+    f = np.clip(0.5 + 0.25 * np.stack([smooth_field(rng, (ny, nx), 1.0, 3) for _ in range(nc)], axis=2)
+                + 0.05 * rng.normal(size=(ny, nx, nc)), 0.0, 1.0)
+    v = np.zeros((Ny, Nx, max(nc - 1, 0), 2))
+    for i in range(nc - 1):
+        for comp in range(2):
+            if flow == "smooth":
+                v[:, :, i, comp] = smooth_field(rng, (Ny, Nx), flow_scale)
+            elif flow == "random":
+                v[:, :, i, comp] = rng.normal(0.0, flow_scale, (Ny, Nx))
+            elif flow == "integer":
+                v[:, :, i, comp] = np.round(smooth_field(rng, (Ny, Nx), flow_scale))
+            elif flow == "zero":
+                pass
+            else:
+                raise ValueError(flow)
+    occ = None
+    if with_occ and nc > 1:
+        occ = (rng.random((Ny, Nx, nc - 1)) < 0.1).astype(np.uint8)
+    return f, v.astype(np.float32).astype(np.float64), occ
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))

@@ -1,0 +1,126 @@
+"""GPU parity of the matrix-free operators and step sizes against the explicit
+sparse matrices of the oracle (oracle/mmc_oracle.py), through the C ABI."""
+import numpy as np
+import pytest
+
+import mmc_oracle as orc
+from helpers import make_case, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+KBLUR = orc.fspecial_gaussian(7, np.sqrt(0.6))
+DIRS = ["backward", "forward", "forward-backward"]
+KAPPAS = [0.25, 1.0, float("nan")]
+
+
+def _solver(f, v, occ, kappa, direction, k, P, sampling="average", factor=4):
+    from superresolution_amd.solver import FrameBlockSolver
+    ny, nx, nc = f.shape
+    s = FrameBlockSolver(ny, nx, factor, nc, alpha=P.alpha, kappa=kappa, h=P.h,
+                         flow_direction=direction, sampling=sampling)
+    s.set_lowres(f)
+    s.set_blur(k)
+    s.set_flow(v, occ)
+    s.set_state(P.u_up, P.u_up)
+    s.init()
+    return s
+
+
+def _split_y(P, y):
+    out, off = {}, 0
+    for name, size, kind, par in P.dual_blocks:
+        out[name] = y[off:off + size]
+        off += size
+    return out
+
+
+@pytest.mark.parametrize("direction", DIRS)
+@pytest.mark.parametrize("kappa", KAPPAS)
+@pytest.mark.parametrize("flow", ["smooth", "random", "integer"])
+def test_forward_adjoint_steps(direction, kappa, flow):
+    f, v, occ = make_case(11, 9, 7, 4, flow=flow, flow_scale=2.5, with_occ=(flow == "smooth"))
+    P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
+    s = _solver(f, v, occ, kappa, direction, KBLUR, P)
+    rng = np.random.default_rng(5)
+    Ny, Nx, nc = P.dims[:3]
+    M = P.M
+
+    # K x
+    x = rng.normal(size=P.K.shape[1])
+    u = x[:M].reshape((Ny, Nx, nc), order="F")
+    w = x[M:2 * M].reshape((Ny, Nx, nc), order="F") if len(P.primal) == 2 else None
+    p, g1, g2 = s.debug_apply_K(u, w)
+    ref = _split_y(P, P.K @ x)
+    assert rel_l2(p, ref["p"]) < 2e-6
+    assert rel_l2(g1, ref["g1"]) < 2e-6
+    if "g2" in ref:
+        assert rel_l2(g2, ref["g2"]) < 2e-6
+
+    # K' y  (temporal duals of masked rows are structurally zero in the solve)
+    y = rng.normal(size=P.K.shape[0])
+    rowzero = np.asarray(abs(P.K).sum(axis=1)).ravel() == 0
+    y[rowzero] = 0.0
+    yb = _split_y(P, y)
+    ku, kw = s.debug_apply_KT(yb["p"], yb["g1"], yb.get("g2"))
+    refx = P.KT @ y
+    assert rel_l2(ku, refx[:M]) < 2e-6
+    if kw is not None:
+        assert rel_l2(kw, refx[M:2 * M]) < 2e-6
+
+    # adjointness through the device operators alone
+    lhs = float(np.dot(np.concatenate([p, g1] + ([g2] if g2 is not None else [])).astype(np.float64), y))
+    rhs = float(np.dot(np.concatenate([ku] + ([kw] if kw is not None else [])).astype(np.float64), x))
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0)
+
+    # step sizes
+    tu, tw, sp, s1, s2 = s.debug_steps()
+    assert rel_l2(tu, P.T[:M]) < 1e-6
+    if tw is not None:
+        assert rel_l2(tw, P.T[M:2 * M]) < 1e-6
+    S = _split_y(P, P.S)
+    assert rel_l2(sp, S["p"]) < 1e-6
+    if np.isnan(kappa):
+        assert rel_l2(s1, S["g1"]) < 1e-6
+        assert rel_l2(s2, S["g2"][:M]) < 1e-6
+    else:
+        assert rel_l2(s1, S["g1"][:M]) < 1e-6
+        if "g2" in S:
+            assert rel_l2(s2, S["g2"][:M]) < 1e-6
+    s.close()
+
+
+@pytest.mark.parametrize("sampling,k", [("stride", None), ("average", None), ("stride", KBLUR),
+                                        ("average", np.random.default_rng(3).random((5, 3)))])
+def test_data_operator_variants(sampling, k):
+    """'stride' sampling, no blur, and a non-square non-symmetric blur kernel."""
+    f, v, _ = make_case(2, 6, 8, 2)
+    P = orc.build_problem(f, v, k=k, interpMethod=sampling)
+    s = _solver(f, v, None, 0.25, "backward", k, P, sampling=sampling)
+    rng = np.random.default_rng(1)
+    Ny, Nx, nc = P.dims[:3]
+    x = rng.normal(size=P.K.shape[1])
+    u = x[:P.M].reshape((Ny, Nx, nc), order="F")
+    w = x[P.M:].reshape((Ny, Nx, nc), order="F")
+    p, g1, g2 = s.debug_apply_K(u, w)
+    ref = _split_y(P, P.K @ x)
+    assert rel_l2(p, ref["p"]) < 2e-6
+    y = rng.normal(size=P.K.shape[0])
+    y[np.asarray(abs(P.K).sum(axis=1)).ravel() == 0] = 0
+    yb = _split_y(P, y)
+    ku, kw = s.debug_apply_KT(yb["p"], yb["g1"], yb["g2"])
+    refx = P.KT @ y
+    assert rel_l2(ku, refx[:P.M]) < 2e-6
+    tu, tw, sp, s1, s2 = s.debug_steps()
+    assert rel_l2(tu, P.T[:P.M]) < 1e-6
+    assert rel_l2(sp, _split_y(P, P.S)["p"]) < 1e-6
+    s.close()
+
+
+def test_h_matches_oracle():
+    f, v, _ = make_case(4, 8, 8, 3)
+    P = orc.build_problem(f, v, k=KBLUR)
+    from superresolution_amd.solver import FrameBlockSolver
+    s = FrameBlockSolver(8, 8, 4, 3, h=0.0)
+    s.set_lowres(f); s.set_blur(KBLUR); s.set_flow(v); s.set_state(P.u_up, P.u_up); s.init()
+    assert abs(s.h - P.h) <= 1e-5 * P.h
+    s.close()
