@@ -418,7 +418,12 @@ def build_problem(f_lr, v, factor=4, alpha=0.01, kappa=0.25, flowDirection='back
     uu = u_up.ravel(order='F')
     P.warpPix = np.abs(W @ uu).sum() / uu.size                                           # :432
     P.gradPix = np.abs(G @ uu).sum() / uu.size                                           # :435
-    P.h = float(h) if (h is not None and h > 0) else P.warpPix / P.gradPix               # :437
+    if h is not None and h > 0:
+        P.h = float(h)
+    elif nc == 1:
+        P.h = 1.0           # no temporal rows at all; the reference's 0/x would only scale an empty W
+    else:
+        P.h = P.warpPix / P.gradPix                                                      # :437
     hh = P.h
 
     A = sp.kron(sp.identity(nc), P.dsOp, format='csr')                                   # :487 id_kron_sparse
