@@ -181,6 +181,16 @@ int mmc_sums_read(mmc_handle *h, double out[MMC_NUM_SUMS]);   /* synchronises */
 int mmc_halo_info(mmc_handle *h, mmc_halo *out);
 int mmc_sync(mmc_handle *h);
 
+/* Per-kernel timing of mmc_solve with HIP events recorded on the library's
+ * stream around every launch (the reference only has tic/toc around run,
+ * testfile.m:66-68).  With profiling enabled the next mmc_solve times up to
+ * the first 512 iterations; mmc_get_profile then returns the average
+ * duration in milliseconds of [0] the primal sweep kernel, [1] the dual
+ * (regulariser) kernel, [2] the dual (data term) kernel, and the number of
+ * iterations averaged. */
+int mmc_set_profiling(mmc_handle *h, int enable);
+int mmc_get_profile(mmc_handle *h, double out_ms[3], int *iterations);
+
 /* Result extraction, MultiframeMotionCoupling.m:983-986: u and w of the local
  * frames (w may be NULL). */
 int mmc_get_state(mmc_handle *h, float *u, float *w);

@@ -79,6 +79,8 @@ SIGNATURES = {
     "mmc_sums_read": (C.c_int, [_H, _dp]),
     "mmc_halo_info": (C.c_int, [_H, C.POINTER(mmc_halo)]),
     "mmc_sync": (C.c_int, [_H]),
+    "mmc_set_profiling": (C.c_int, [_H, C.c_int]),
+    "mmc_get_profile": (C.c_int, [_H, _dp, C.POINTER(C.c_int)]),
     "mmc_get_state": (C.c_int, [_H, _fp, _fp]),
     "mmc_energy": (C.c_int, [_H, _dp]),
     "mmc_debug_apply_K": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),

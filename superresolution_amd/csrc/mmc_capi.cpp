@@ -5,6 +5,7 @@
 #include "../../include/mmc_hip.h"
 #include "mmc_internal.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -27,7 +28,13 @@ struct mmc_handle {
     float h = 1.f;
     std::vector<void *> allocs;
     std::string err;
+    bool profiling = false;
+    std::vector<hipEvent_t> events;       // 4 per profiled iteration
+    double prof_ms[3] = {0, 0, 0};
+    int prof_iters = 0;
 };
+
+enum { PROF_MAX_ITERS = 512 };
 
 static thread_local std::string g_create_err;
 
@@ -162,6 +169,7 @@ extern "C" int mmc_destroy(mmc_handle *h) {
     hipSetDevice(h->prm.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
+    for (hipEvent_t e : h->events) hipEventDestroy(e);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return MMC_OK;
@@ -481,11 +489,25 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const auto t_start = std::chrono::steady_clock::now();
     const Geom &g = h->g;
+    int prof_n = 0;
+    if (h->profiling) {
+        const size_t need = (size_t)4 * std::min(max_iters, (int)PROF_MAX_ITERS);
+        while (h->events.size() < need) {
+            hipEvent_t e;
+            HIPCHK(h, hipEventCreate(&e));
+            h->events.push_back(e);
+        }
+    }
     for (int it = 0; it < max_iters; ++it) {
         const bool check = ((it + 1) % check_every == 0) || it == max_iters - 1;
         if (check && (rc = zero_sums(h))) return rc;
+        const bool prof = h->profiling && it < PROF_MAX_ITERS;
+        hipEvent_t *ev = prof ? &h->events[(size_t)4 * it] : nullptr;
+        if (prof) HIPCHK(h, hipEventRecord(ev[0], h->stream));
         HIPCHK(h, mmc_launch_primal(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream));
-        HIPCHK(h, mmc_launch_dual(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream));
+        if (prof) HIPCHK(h, hipEventRecord(ev[1], h->stream));
+        HIPCHK(h, mmc_launch_dual(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream, prof ? ev[2] : nullptr));
+        if (prof) { HIPCHK(h, hipEventRecord(ev[3], h->stream)); prof_n = it + 1; }
         st.iterations = it + 1;
         if (check) {
             double s[MMC_NUM_SUMS];
@@ -498,7 +520,35 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     st.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (h->profiling) {
+        prof_n = std::min(prof_n, st.iterations);
+        double acc[3] = {0, 0, 0};
+        for (int it = 0; it < prof_n; ++it) {
+            hipEvent_t *ev = &h->events[(size_t)4 * it];
+            for (int k = 0; k < 3; ++k) {
+                float ms = 0.f;
+                HIPCHK(h, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+                acc[k] += ms;
+            }
+        }
+        for (int k = 0; k < 3; ++k) h->prof_ms[k] = prof_n ? acc[k] / prof_n : 0.0;
+        h->prof_iters = prof_n;
+    }
     if (stats) *stats = st;
+    return MMC_OK;
+}
+
+extern "C" int mmc_set_profiling(mmc_handle *h, int enable) {
+    REQUIRE_HANDLE(h);
+    h->profiling = enable != 0;
+    return MMC_OK;
+}
+
+extern "C" int mmc_get_profile(mmc_handle *h, double out_ms[3], int *iterations) {
+    REQUIRE_HANDLE(h);
+    if (!out_ms) return fail(h, MMC_ERR_INVALID_ARG, "mmc_get_profile: null output");
+    for (int k = 0; k < 3; ++k) out_ms[k] = h->prof_ms[k];
+    if (iterations) *iterations = h->prof_iters;
     return MMC_OK;
 }
 

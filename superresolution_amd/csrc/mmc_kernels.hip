@@ -562,12 +562,14 @@ static void launch_dual_m(const Geom &g, const Arrays &a, int t0, int nf, int mo
     else hipLaunchKernelGGL((k_dual<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
 }
 
-hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s) {
+hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s,
+                           hipEvent_t mid) {
     if (t1 <= t0) return hipSuccess;
     const int nf = t1 - t0;
     if (g.model == MODEL_IC) launch_dual_m<MODEL_IC>(g, a, t0, nf, mode, reduce, s);
     else if (g.model == MODEL_K1) launch_dual_m<MODEL_K1>(g, a, t0, nf, mode, reduce, s);
     else launch_dual_m<MODEL_ADD>(g, a, t0, nf, mode, reduce, s);
+    if (mid) (void)hipEventRecord(mid, s);
     const size_t total = (size_t)g.n * nf;
     dim3 gridp((unsigned)((total + MMC_THREADS - 1) / MMC_THREADS)), block(MMC_THREADS);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual_p<MODE_RAW, false>), gridp, block, 0, s, g, a, t0, nf);

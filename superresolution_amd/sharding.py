@@ -1,0 +1,177 @@
+"""Frame-block sharding of one sequence over several GPUs (one process each).
+
+The motion-coupling operator only couples frame t with frame t+1
+(helpers/constructWarpFF.m:40-58), blur/sampling and the spatial gradient act
+inside a frame.  Rank r therefore owns a contiguous block of frames with all
+their primal and dual variables, and per PDHG iteration exchanges exactly two
+frame-sized messages with each chain neighbour:
+
+  after the primal sweep   xbar of its FIRST frame      -> previous rank
+  after the dual sweep     temporal duals of its LAST   -> next rank
+                           frame (pair last|next)
+
+Point-to-point over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo"
+in the CPU tests).  Each exchange is posted right after the frames it sends are
+final and is only waited for before the one frame that needs the ghost, so it
+overlaps with the sweep over the interior frames.
+"""
+import numpy as np
+
+
+def partition_frames(nc, world):
+    """Contiguous blocks [begin, end) for each rank; remainders go to the first ranks."""
+    if world <= 0 or nc < world:
+        raise ValueError("need at least one frame per rank (nc=%d, world=%d)" % (nc, world))
+    base, rem = divmod(nc, world)
+    out, b = [], 0
+    for r in range(world):
+        e = b + base + (1 if r < rem else 0)
+        out.append((b, e))
+        b = e
+    return out
+
+
+def pairs_needed(begin, end, nc):
+    """Global flow pairs [lo, hi) a block touches: its own and the previous block's last."""
+    lo = begin - 1 if begin > 0 else 0
+    hi = min(end, nc - 1)
+    return lo, max(hi, lo)
+
+
+def state_frames_needed(begin, end, nc):
+    """Frames whose start point a block needs: its own plus the next block's first."""
+    return begin, min(end + 1, nc)
+
+
+class DeviceBuffer(object):
+    """Zero-copy view of `count` float32 at device address `ptr` for torch.as_tensor."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4",
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def halo_tensors(solver):
+    """Torch views of the frames a FrameBlockSolver exchanges (see include/mmc_hip.h: mmc_halo)."""
+    import torch
+    hl = solver.halo_info()
+    count = hl.frame_bytes // 4
+    dev = "cuda:%d" % solver.params.device
+
+    def view(p):
+        return None if not p else torch.as_tensor(DeviceBuffer(p, count), device=dev)
+
+    return {name: [view(getattr(hl, name)[i]) for i in range(2)]
+            for name in ("send_prev", "recv_next", "send_next", "recv_prev")}
+
+
+class HaloExchanger(object):
+    """Posts the two per-iteration exchanges of one block as batched isend/irecv."""
+
+    def __init__(self, tensors, rank, world, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.t = tensors
+        self.prev = rank - 1 if rank > 0 else None
+        self.next = rank + 1 if rank < world - 1 else None
+        self.group = group
+
+    def _post(self, ops):
+        if not ops:
+            return []
+        return self.dist.batch_isend_irecv(ops)
+
+    def start_xbar(self):
+        P2POp, d = self.dist.P2POp, self.dist
+        ops = []
+        if self.prev is not None:
+            ops += [P2POp(d.isend, t, self.prev, self.group) for t in self.t["send_prev"] if t is not None]
+        if self.next is not None:
+            ops += [P2POp(d.irecv, t, self.next, self.group) for t in self.t["recv_next"] if t is not None]
+        return self._post(ops)
+
+    def start_dual(self):
+        P2POp, d = self.dist.P2POp, self.dist
+        ops = []
+        if self.next is not None:
+            ops += [P2POp(d.isend, t, self.next, self.group) for t in self.t["send_next"] if t is not None]
+        if self.prev is not None:
+            ops += [P2POp(d.irecv, t, self.prev, self.group) for t in self.t["recv_prev"] if t is not None]
+        return self._post(ops)
+
+    @staticmethod
+    def wait(reqs):
+        for r in reqs or []:
+            r.wait()
+
+
+def allreduce_sums(values, device=None):
+    """Sum a short float64 vector over all ranks; returns a numpy array."""
+    import torch
+    import torch.distributed as dist
+    t = torch.as_tensor(np.asarray(values, dtype=np.float64))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t)
+    return t.cpu().numpy()
+
+
+def sharded_h(engine, device=None):
+    """h = sum|W u0| / sum|grad u0| over the whole sequence (MultiframeMotionCoupling.m:431-437)."""
+    s = allreduce_sums(engine.h_partials(), device)
+    if not (s[0] > 0 and s[1] > 0):
+        raise ValueError("warp or gradient energy of the start point is zero; pass h explicitly")
+    return float(s[0] / s[1])
+
+
+def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=None, callback=None):
+    """The loop of mmc_solve for a block with neighbours.
+
+    `engine` provides L, sweep_primal(t0,t1,reduce), sweep_dual(t0,t1,reduce),
+    sums_reset(), sums_read() and sync(); FrameBlockSolver does.  Ghost duals
+    start at zero on both sides, matching the zero start of the duals.
+    """
+    L = engine.L
+    has_prev = exchanger.prev is not None
+    has_next = exchanger.next is not None
+    if check_every <= 0:
+        check_every = max(max_iters, 1)
+    stats = {"iterations": 0, "converged": False, "res_primal": 0.0, "res_dual": 0.0}
+    reqs_dual = []
+    for it in range(max_iters):
+        check = ((it + 1) % check_every == 0) or it == max_iters - 1
+        if check:
+            engine.sums_reset()
+        # primal sweep: the first frame needs the previous block's temporal duals
+        if has_prev:
+            engine.sweep_primal(1, L, check)
+            exchanger.wait(reqs_dual)
+            engine.sweep_primal(0, 1, check)
+        else:
+            exchanger.wait(reqs_dual)
+            engine.sweep_primal(0, L, check)
+        reqs_x = exchanger.start_xbar()
+        # dual sweep: the last frame needs the next block's xbar
+        if has_next:
+            engine.sweep_dual(0, L - 1, check)
+            exchanger.wait(reqs_x)
+            engine.sweep_dual(L - 1, L, check)
+        else:
+            engine.sweep_dual(0, L, check)
+            exchanger.wait(reqs_x)
+        reqs_dual = exchanger.start_dual()
+        stats["iterations"] = it + 1
+        if check:
+            s = allreduce_sums(engine.sums_read(), device)
+            tiny = 1e-30
+            stats["res_primal"] = float(np.sqrt(s[0]) / max(np.sqrt(s[1]), tiny))
+            stats["res_dual"] = float(np.sqrt(s[2]) / max(np.sqrt(s[3]), tiny))
+            stop = callback(it + 1, stats) if callback is not None else False
+            if stop:
+                break
+            if tol > 0 and stats["res_primal"] < tol and stats["res_dual"] < tol:
+                stats["converged"] = True
+                break
+    exchanger.wait(reqs_dual)
+    engine.sync()
+    return stats

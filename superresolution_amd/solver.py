@@ -185,6 +185,16 @@ class FrameBlockSolver(object):
     def sync(self):
         self._check(self._lib.mmc_sync(self._h))
 
+    def set_profiling(self, enable=True):
+        self._check(self._lib.mmc_set_profiling(self._h, int(bool(enable))))
+
+    def get_profile(self):
+        """Average kernel durations (ms) of the last profiled solve."""
+        ms = (C.c_double * 3)()
+        n = C.c_int()
+        self._check(self._lib.mmc_get_profile(self._h, ms, C.byref(n)))
+        return {"primal_ms": ms[0], "dual_reg_ms": ms[1], "dual_data_ms": ms[2], "iterations": n.value}
+
     def energy(self):
         v = C.c_double()
         self._check(self._lib.mmc_energy(self._h, C.byref(v)))
