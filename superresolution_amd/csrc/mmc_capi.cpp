@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <limits.h>
 #include <string>
 #include <vector>
@@ -141,6 +142,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     g.tiles_c = (g.Nx + TILE_C - 1) / TILE_C;
     g.ntiles = g.tiles_r * g.tiles_c;
     g.inv_h = 1.f;
+    if (const char *e = getenv("MMC_DEBUG")) g.dbg = atoi(e);
     if (p->h > 0.f) { h->h = p->h; h->have_h = true; g.inv_h = 1.f / p->h; }
 
     Arrays &a = h->a;
@@ -157,6 +159,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     if ((rc = dev_alloc(h, &a.cA, (size_t)g.N)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.sigp, (size_t)g.n)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.ckp, (size_t)(MMC_MAX_CK + p->factor) * (MMC_MAX_CK + p->factor))) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.bbox, (size_t)(h->L + 1) * g.ntiles * 4)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)) != MMC_OK) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MMC_ERR_HIP); }
@@ -282,6 +285,14 @@ static int build_data_operator(mmc_handle *h) {
                     ck[(size_t)(aa + i) + (size_t)g.CH * (b + j)] += wd * wd * kv;
                 }
     std::vector<float> ckf(ck.begin(), ck.end());
+    g.Jr = (g.CH + g.f - 1) / g.f; g.Jc = (g.CW + g.f - 1) / g.f;
+    g.MP = g.f * g.Jr; g.NP = g.f * g.Jc;
+    g.PR = (TILE_R - 1) / g.f + g.Jr + 1; g.PC = (TILE_C - 1) / g.f + g.Jc + 1;
+    std::vector<float> ckpad((size_t)g.MP * g.NP, 0.f);
+    for (int nn = 0; nn < g.CW; ++nn)
+        for (int mm = 0; mm < g.CH; ++mm) ckpad[(size_t)mm + (size_t)g.MP * nn] = ckf[(size_t)mm + (size_t)g.CH * nn];
+    HIPCHK(h, hipMemcpyAsync(h->a.ckp, ckpad.data(), ckpad.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<double> colsum((size_t)g.N, 0.0);
     std::vector<float> sig((size_t)g.n);
     std::vector<double> merged((size_t)g.CH * g.CW);

@@ -25,9 +25,13 @@ struct Geom {
     int dir;                   // mmc_flow_direction
     int model;                 // MODEL_*
     int CH, CW, oy, ox;        // composite kernel size; first tap sits at f*R+oy, f*C+ox
+    int Jr, Jc;                // low-res taps per axis of the adjoint: ceil(CH/f), ceil(CW/f)
+    int MP, NP;                // zero-padded composite kernel table: f*Jr x f*Jc
+    int PR, PC;                // low-res window staged per tile
     int tiles_r, tiles_c, ntiles;
     float alpha, kappa, inv_h;
     float radius1, radius2;    // projection radii of the g1 / g2 groups
+    int dbg;                   // ablation switches for kernel tuning (env MMC_DEBUG), 0 in production
 };
 
 // Every per-pixel array holds L+2 frames: slot 0 is the ghost of the previous
@@ -44,6 +48,7 @@ struct Arrays {
     float *cA;                 // column abs-sum of D*B, N
     float *sigp;               // 1 / row abs-sum of D*B, n
     float *cker;               // composite kernel, CH x CW column-major
+    float *ckp;                // the same, zero-padded to MP x NP
     int *bbox;                 // [(L+1) pair slots][ntiles][4] = rmin,rmax,cmin,cmax
     double *sums;              // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]
 };

@@ -74,6 +74,25 @@ __device__ __forceinline__ float sample(const Taps &t, const float *img) {
     return t.w00 * img[t.i00] + t.w10 * img[t.i10] + t.w01 * img[t.i01] + t.w11 * img[t.i11];
 }
 
+
+// The adjoint of the bilinear warp scatters.  Sums are accumulated in LDS as
+// 64-bit fixed point (scale 2^40): integer LDS atomics run at full LDS rate on
+// gfx950 whereas float LDS atomics take about 3 clocks per lane, integer sums do
+// not depend on arrival order (runs are bitwise reproducible), and 2^-40 is far
+// below float32 resolution for any |value| < 2^23.
+typedef unsigned long long fx64;
+__device__ __forceinline__ fx64 to_fx(float x) {
+    const float t = x * 256.f;                      // exact
+    const float hi = floorf(t);
+    const unsigned lo = (unsigned)((t - hi) * 4294967296.f);
+    return ((fx64)(unsigned)(int)hi << 32) | (fx64)lo;
+}
+__device__ __forceinline__ float from_fx(fx64 v) {
+    const double d = (double)(int)(unsigned)(v >> 32) * 4294967296.0 + (double)(unsigned)(v & 0xffffffffull);
+    return (float)(d * (1.0 / 1099511627776.0));
+}
+__device__ __forceinline__ void fx_add(fx64 *acc, float x) { atomicAdd(acc, to_fx(x)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -151,8 +170,8 @@ __device__ __forceinline__ float grad_adj(const Geom &g, const float *__restrict
 // MODE_STEPS : ub,wb <- tau_u, tau_w  (test hook)
 template <int MODEL, int MODE, bool REDUCE>
 __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0) {
-    __shared__ float acc1[TILE_R * TILE_C];
-    __shared__ float acc2[TILE_R * TILE_C];
+    __shared__ fx64 acc1[TILE_R * TILE_C];
+    __shared__ fx64 acc2[TILE_R * TILE_C];
     const int t = t0 + blockIdx.y;
     const int tile = blockIdx.x;
     const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
@@ -160,8 +179,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
 
     for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) {
-        acc1[k] = 0.f;
-        if (MODEL == MODEL_IC) acc2[k] = 0.f;
+        acc1[k] = 0;
+        if (MODEL == MODEL_IC) acc2[k] = 0;
     }
     __syncthreads();
 
@@ -189,10 +208,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
                 const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
                 const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
                 const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
-                if (ra0 && cb0) { atomicAdd(&acc1[a0 + TILE_R * b0], tp.w00 * s1); if (MODEL == MODEL_IC) atomicAdd(&acc2[a0 + TILE_R * b0], tp.w00 * s2); }
-                if (ra1 && cb0) { atomicAdd(&acc1[a1 + TILE_R * b0], tp.w10 * s1); if (MODEL == MODEL_IC) atomicAdd(&acc2[a1 + TILE_R * b0], tp.w10 * s2); }
-                if (ra0 && cb1) { atomicAdd(&acc1[a0 + TILE_R * b1], tp.w01 * s1); if (MODEL == MODEL_IC) atomicAdd(&acc2[a0 + TILE_R * b1], tp.w01 * s2); }
-                if (ra1 && cb1) { atomicAdd(&acc1[a1 + TILE_R * b1], tp.w11 * s1); if (MODEL == MODEL_IC) atomicAdd(&acc2[a1 + TILE_R * b1], tp.w11 * s2); }
+                if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00 * s2); }
+                if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10 * s2); }
+                if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01 * s2); }
+                if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11 * s2); }
             }
         }
         __syncthreads();
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
             if (MODEL == MODEL_IC) wb[j] = tau_w;
             continue;
         }
-        float Wt1 = acc1[k], Wt2 = (MODEL == MODEL_IC) ? acc2[k] : 0.f;
+        float Wt1 = from_fx(acc1[k]), Wt2 = (MODEL == MODEL_IC) ? from_fx(acc2[k]) : 0.f;
         if (idA) {
             const float s1 = idA1[j];
             Wt1 -= s1;
@@ -265,6 +284,260 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
             w[j] = wn;
             wb[j] = 2.f * wn - wo;
             if (REDUCE) { part[0] += (wn - wo) * (wn - wo); part[1] += wn * wn; }
+        }
+    }
+    if (REDUCE) block_accumulate<2>(part, a.sums, 0);
+}
+
+// --------------------------------------------------------------------------
+// primal sweep, row-quad form (Ny % 4 == 0)
+// --------------------------------------------------------------------------
+// Same arithmetic as k_primal; each thread owns four consecutive rows of one
+// column so that every per-pixel array moves as one 16-byte access per lane.
+// The low-res dual p of the tile and a zero-padded copy of the composite
+// kernel sit in LDS, which makes the interior A'p a branch-free Jr x Jc sum:
+// tap (jr,jc) of pixel row x = r - oy uses low-res row R = x/f - jr with
+// kernel row (x mod f) + f*jr; rows of the table beyond CH and low-res pixels
+// outside the frame hold zeros.
+__device__ __forceinline__ void ld4(float (&d)[4], const float *p) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+}
+__device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(s[0], s[1], s[2], s[3]);
+}
+
+template <int MODEL, int MODE, bool REDUCE, int F>
+__global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t0) {
+    extern __shared__ __align__(16) float lds[];
+    fx64 *acc1 = reinterpret_cast<fx64 *>(lds);
+    fx64 *acc2 = acc1 + TILE_R * TILE_C;
+    float *ckp = lds + 4 * TILE_R * TILE_C;
+    float *pl = ckp + g.MP * g.NP;
+    const int f = F > 0 ? F : g.f;
+    const int tid = threadIdx.x;
+    const int t = t0 + blockIdx.y;
+    const int tile = blockIdx.x;
+    const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+    const int r0 = tr * TILE_R, c0 = tc * TILE_C;
+    const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
+    const float *p = a.p + (size_t)t * g.n;
+    const int Rbase = (r0 - g.oy) / f - (g.Jr - 1);
+    const int Cbase = (c0 - g.ox) / f - (g.Jc - 1);
+
+    // This thread's row quad.  Its own loads are issued first: they do not
+    // depend on the scatter below and stay in flight across the barriers.
+    const int rq = tid & (TILE_R / 4 - 1), lc = tid / (TILE_R / 4);
+    const int r = r0 + 4 * rq, c = c0 + lc;
+    const bool active = r < g.Ny && c < g.Nx;
+    const int j = active ? r + g.Ny * c : 0;
+    const bool cl = c > 0, cr = c < g.Nx - 1;
+    const bool idA = pair_exists(g, t) && pair_is_IF(g, t);            // -Id of pair t sits on this frame
+    const bool idB = pair_exists(g, t - 1) && !pair_is_IF(g, t - 1);   // -Id of pair t-1
+    float uo[4], wo[4], cWv[4], cAv[4];
+    float gx1[4], gl1[4] = {0.f, 0.f, 0.f, 0.f}, gy1[4], up1 = 0.f;
+    float gx2[4], gl2[4] = {0.f, 0.f, 0.f, 0.f}, gy2[4], up2 = 0.f;
+    float sA1[4] = {0.f, 0.f, 0.f, 0.f}, sA2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        ld4(cWv, FR(a.cW, t) + j);
+        ld4(cAv, a.cA + j);
+        if (MODE == MODE_UPDATE) {
+            ld4(uo, FR(a.u, t) + j);
+            if (MODEL == MODEL_IC) ld4(wo, FR(a.w, t) + j);
+        }
+        if (MODE != MODE_STEPS) {
+            const float *g1x = FR(a.g1x, t) + j, *g1y = FR(a.g1y, t) + j;
+            ld4(gx1, g1x);
+            if (cl) ld4(gl1, g1x - g.Ny);
+            ld4(gy1, g1y);
+            if (r > 0) up1 = g1y[-1];
+            if (MODEL == MODEL_IC) {
+                const float *g2x = FR(a.g2x, t) + j, *g2y = FR(a.g2y, t) + j;
+                ld4(gx2, g2x);
+                if (cl) ld4(gl2, g2x - g.Ny);
+                ld4(gy2, g2y);
+                if (r > 0) up2 = g2y[-1];
+            }
+            if (idA) {
+                ld4(sA1, FR(a.g1t, t) + j);
+                if (MODEL == MODEL_IC) ld4(sA2, FR(a.g2t, t) + j);
+            }
+        }
+    }
+
+    for (int k = tid; k < TILE_R * TILE_C; k += MMC_THREADS) {
+        acc1[k] = 0;
+        if (MODEL == MODEL_IC) acc2[k] = 0;
+    }
+    if (MODE != MODE_STEPS) {
+        for (int k = tid; k < g.MP * g.NP; k += MMC_THREADS) ckp[k] = a.ckp[k];
+        for (int k = tid; k < g.PR * g.PC; k += MMC_THREADS) {
+            const int pc = k / g.PR, pr = k - pc * g.PR;
+            const int R = Rbase + pr, C = Cbase + pc;
+            pl[k] = (R >= 0 && R < g.ny && C >= 0 && C < g.nx) ? p[R + g.ny * C] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // --- scatter part of W': walk the source box of this tile ----------------
+    // SCU source pixels per thread and pass, all their loads issued before the
+    // first use so that one pass costs one memory round trip.
+    if (MODE != MODE_STEPS) {
+        constexpr int SCU = 5;
+        for (int which = 0; which < 2; ++which) {
+            const int q = which == 0 ? t - 1 : t;
+            if (!pair_exists(g, q)) continue;
+            const bool isIF = pair_is_IF(g, q);
+            if ((which == 0) != isIF) continue;
+            const int *bb = a.bbox + ((size_t)(q + 1) * g.ntiles + tile) * 4;
+            const int rmin = bb[0], rmax = bb[1], cmin = bb[2], cmax = bb[3];
+            if (rmax < rmin || cmax < cmin) continue;
+            if (g.dbg & 1) continue;
+            const int nr = rmax - rmin + 1, total = nr * (cmax - cmin + 1);
+            const float inv_nr = 1.f / (float)nr;
+            const float *vx = FR(a.vx, q), *vy = FR(a.vy, q);
+            const float *s1p = FR(a.g1t, q), *s2p = FR(a.g2t, q);
+            for (int base = tid; base < total; base += MMC_THREADS * SCU) {
+                int sr[SCU], sc[SCU];
+                float fvx[SCU], fvy[SCU], fs1[SCU], fs2[SCU];
+#pragma unroll
+                for (int k = 0; k < SCU; ++k) {
+                    const int idx = min(base + k * MMC_THREADS, total - 1);
+                    int cc = (int)(((float)idx + 0.5f) * inv_nr);
+                    int rr = idx - cc * nr;
+                    if (rr < 0) { --cc; rr += nr; }
+                    if (rr >= nr) { ++cc; rr -= nr; }
+                    sr[k] = rmin + rr;
+                    sc[k] = cmin + cc;
+                    const int js = sr[k] + g.Ny * sc[k];
+                    fvx[k] = vx[js];
+                    fvy[k] = vy[js];
+                    fs1[k] = s1p[js];
+                    fs2[k] = (MODEL == MODEL_IC) ? s2p[js] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < SCU; ++k) {
+                    if (base + k * MMC_THREADS >= total) continue;
+                    Taps tp = make_taps(g, sr[k], sc[k], fvx[k], fvy[k]);
+                    if (!tp.valid) continue;
+                    const float s1 = fs1[k];
+                    const float s2 = (MODEL == MODEL_IC) ? kap * fs2[k] - s1 : 0.f;
+                    const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
+                    const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
+                    const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
+                    if (g.dbg & 2) { if (s1 == 12345.f && ra0 && cb1) acc1[0] = to_fx(s2); continue; }
+                    if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00 * s2); }
+                    if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10 * s2); }
+                    if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01 * s2); }
+                    if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11 * s2); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    float part[2] = {0.f, 0.f};
+    if (active) {
+        float *u = FR(a.u, t) + j, *w = FR(a.w, t) + j, *ub = FR(a.ub, t) + j, *wb = FR(a.wb, t) + j;
+        float tau_u[4], tau_w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float cgrad = (float)((int)cl + (int)cr + (int)(r + i > 0) + (int)(r + i < g.Ny - 1));
+            const float cw = cWv[i] * g.inv_h;
+            if (MODEL == MODEL_IC) {
+                tau_u[i] = 1.f / (cAv[i] + cw + kap * cgrad);
+                tau_w[i] = 1.f / ((1.f + kap) * (cw + cgrad));
+            } else {
+                tau_u[i] = 1.f / (cAv[i] + cw + cgrad);
+                tau_w[i] = 0.f;
+            }
+        }
+        if (MODE == MODE_STEPS) {
+            st4(ub, tau_u);
+            if (MODEL == MODEL_IC) st4(wb, tau_w);
+        } else {
+            float Wt1[4], Wt2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Wt1[i] = from_fx(acc1[4 * rq + i + TILE_R * lc]);
+                if (MODEL == MODEL_IC) Wt2[i] = from_fx(acc2[4 * rq + i + TILE_R * lc]);
+            }
+            // identity part of W': -g of the pairs whose -Id block sits on this frame
+            if (idA) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { Wt1[i] -= sA1[i]; if (MODEL == MODEL_IC) Wt2[i] -= kap * sA2[i] - sA1[i]; }
+            }
+            if (idB) {
+                float s1[4], s2[4];
+                ld4(s1, FR(a.g1t, t - 1) + j);
+                if (MODEL == MODEL_IC) ld4(s2, FR(a.g2t, t - 1) + j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { Wt1[i] -= s1[i]; if (MODEL == MODEL_IC) Wt2[i] -= kap * s2[i] - s1[i]; }
+            }
+            // G' of the spatial duals
+            float div1[4], div2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool below = r + i < g.Ny - 1;
+                div1[i] = gl1[i] - (cr ? gx1[i] : 0.f) + (i > 0 ? gy1[i > 0 ? i - 1 : 0] : up1) - (below ? gy1[i] : 0.f);
+                if (MODEL == MODEL_IC)
+                    div2[i] = gl2[i] - (cr ? gx2[i] : 0.f) + (i > 0 ? gy2[i > 0 ? i - 1 : 0] : up2) - (below ? gy2[i] : 0.f);
+            }
+            // A'p
+            float ATp[4];
+            const int xc = c - g.ox;
+            const int Chi = xc / f, bc = xc - f * Chi;
+            const bool cborder = !cl || !cr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ri = r + i;
+                if (g.dbg & 4) {
+                    ATp[i] = 0.f;
+                } else if (cborder || ri == 0 || ri == g.Ny - 1) {
+                    ATp[i] = gather_ATp(g, a.cker, p, ri, c);
+                } else {
+                    const int x = ri - g.oy;
+                    const int Rhi = x / f, br = x - f * Rhi;
+                    const float *ck0 = ckp + br + g.MP * bc;
+                    const float *pl0 = pl + (Rhi - Rbase) + g.PR * (Chi - Cbase);
+                    float s = 0.f;
+                    for (int jc = 0; jc < g.Jc; ++jc)
+                        for (int jr = 0; jr < g.Jr; ++jr)
+                            s += ck0[f * jr + g.MP * f * jc] * pl0[-jr - g.PR * jc];
+                    ATp[i] = s;
+                }
+            }
+            float KTu[4], KTw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                KTu[i] = ATp[i] + g.inv_h * Wt1[i] + kap * div1[i];
+                KTw[i] = (MODEL == MODEL_IC) ? g.inv_h * Wt2[i] - kap * div1[i] + div2[i] : 0.f;
+            }
+            if (MODE == MODE_RAW) {
+                st4(ub, KTu);
+                if (MODEL == MODEL_IC) st4(wb, KTw);
+            } else {
+                float un[4], ubn[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    un[i] = fminf(fmaxf(uo[i] - tau_u[i] * KTu[i], 0.f), 1.f);   // G = ind[0,1], :495
+                    ubn[i] = 2.f * un[i] - uo[i];
+                    if (REDUCE) { part[0] += (un[i] - uo[i]) * (un[i] - uo[i]); part[1] += un[i] * un[i]; }
+                }
+                st4(u, un);
+                st4(ub, ubn);
+                if (MODEL == MODEL_IC) {
+                    float wn[4], wbn[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        wn[i] = wo[i] - tau_w[i] * KTw[i];
+                        wbn[i] = 2.f * wn[i] - wo[i];
+                        if (REDUCE) { part[0] += (wn[i] - wo[i]) * (wn[i] - wo[i]); part[1] += wn[i] * wn[i]; }
+                    }
+                    st4(w, wn);
+                    st4(wb, wbn);
+                }
+            }
         }
     }
     if (REDUCE) block_accumulate<2>(part, a.sums, 0);
@@ -544,8 +817,30 @@ static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int 
     else hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
 }
 
+template <int MODEL, int F>
+static void launch_primal4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+    dim3 grid(g.ntiles, nf), block(MMC_THREADS);
+    const size_t lds = (size_t)(4 * TILE_R * TILE_C + g.MP * g.NP + g.PR * g.PC) * sizeof(float);
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0);
+    else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0);
+    else hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0);
+}
+
+template <int F>
+static void launch_primal4(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+    if (g.model == MODEL_IC) launch_primal4_m<MODEL_IC, F>(g, a, t0, nf, mode, reduce, s);
+    else if (g.model == MODEL_K1) launch_primal4_m<MODEL_K1, F>(g, a, t0, nf, mode, reduce, s);
+    else launch_primal4_m<MODEL_ADD, F>(g, a, t0, nf, mode, reduce, s);
+}
+
 hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s) {
     if (t1 <= t0) return hipSuccess;
+    if (g.Ny % 4 == 0) {   // row-quad kernels need 16-byte aligned columns
+        if (g.f == 4) launch_primal4<4>(g, a, t0, t1 - t0, mode, reduce, s);
+        else launch_primal4<0>(g, a, t0, t1 - t0, mode, reduce, s);
+        return hipGetLastError();
+    }
     if (g.model == MODEL_IC) launch_primal_m<MODEL_IC>(g, a, t0, t1 - t0, mode, reduce, s);
     else if (g.model == MODEL_K1) launch_primal_m<MODEL_K1>(g, a, t0, t1 - t0, mode, reduce, s);
     else launch_primal_m<MODEL_ADD>(g, a, t0, t1 - t0, mode, reduce, s);

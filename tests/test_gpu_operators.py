@@ -124,3 +124,36 @@ def test_h_matches_oracle():
     s.set_lowres(f); s.set_blur(KBLUR); s.set_flow(v); s.set_state(P.u_up, P.u_up); s.init()
     assert abs(s.h - P.h) <= 1e-5 * P.h
     s.close()
+
+
+@pytest.mark.parametrize("factor,ny,nx", [(3, 5, 6), (2, 6, 9), (1, 12, 8), (8, 3, 2)])
+def test_other_zoom_factors(factor, ny, nx):
+    """'stride' sampling at zoom factors other than 4: factor 3 gives a row count that is
+    not a multiple of 4 (scalar kernels), 2 / 1 / 8 the generic-factor row-quad kernels."""
+    f, v, _ = make_case(9, ny, nx, 3, factor=factor)
+    k = orc.fspecial_gaussian(5, 1.0)
+    P = orc.build_problem(f, v, factor=factor, k=k, interpMethod="stride")
+    s = _solver(f, v, None, 0.25, "backward", k, P, sampling="stride", factor=factor)
+    rng = np.random.default_rng(1)
+    Ny, Nx, nc = P.dims[:3]
+    x = rng.normal(size=P.K.shape[1])
+    u = x[:P.M].reshape((Ny, Nx, nc), order="F")
+    w = x[P.M:].reshape((Ny, Nx, nc), order="F")
+    p, g1, g2 = s.debug_apply_K(u, w)
+    ref = _split_y(P, P.K @ x)
+    assert rel_l2(p, ref["p"]) < 2e-6 and rel_l2(g1, ref["g1"]) < 2e-6 and rel_l2(g2, ref["g2"]) < 2e-6
+    y = rng.normal(size=P.K.shape[0])
+    y[np.asarray(abs(P.K).sum(axis=1)).ravel() == 0] = 0
+    yb = _split_y(P, y)
+    ku, kw = s.debug_apply_KT(yb["p"], yb["g1"], yb["g2"])
+    refx = P.KT @ y
+    assert rel_l2(ku, refx[:P.M]) < 2e-6 and rel_l2(kw, refx[P.M:]) < 2e-6
+    tu, tw, sp, s1, s2 = s.debug_steps()
+    assert rel_l2(tu, P.T[:P.M]) < 1e-6 and rel_l2(tw, P.T[P.M:]) < 1e-6
+    x2, _, _ = orc.pdhg(P, 40)
+    s.set_state(P.u_up, P.u_up)
+    s.solve(40)
+    uu, ww = s.get_state()
+    u_ref, w_ref = orc.split_primal(P, x2)
+    assert rel_l2(uu, u_ref) < 1e-4
+    s.close()
