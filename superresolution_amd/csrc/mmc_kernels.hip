@@ -724,6 +724,231 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0
 }
 
 // --------------------------------------------------------------------------
+// dual sweep, row-quad form with the data-term update fused in
+// --------------------------------------------------------------------------
+// Needs Ny % 4 == 0 and a zoom factor that divides the tile (whole low-res
+// pixels per tile).  Each thread owns four consecutive rows of one column for
+// the regulariser duals.  The workgroup also stages xbar_u of its tile plus the
+// blur halo in LDS (replicate border applied while staging) and updates the
+// low-res dual p of the tile from it: wave w sums the composite-kernel columns
+// n = w, w+4, ... for every low-res pixel, the four partial sums meet in LDS.
+template <int MODEL, int MODE, bool REDUCE, int F>
+__global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0) {
+    extern __shared__ __align__(16) float lds[];
+    const int f = F > 0 ? F : g.f;
+    const int tid = threadIdx.x;
+    const int t = t0 + blockIdx.y;
+    const int tile = blockIdx.x;
+    const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+    const int r0 = tr * TILE_R, c0 = tc * TILE_C;
+    const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
+    const bool pex = pair_exists(g, t);
+    const bool isIF = pair_is_IF(g, t);
+    const int SR = TILE_R + g.CH - f, SC = TILE_C + g.CW - f;
+    const int LRR = TILE_R / f, LRC = TILE_C / f, nlr = LRR * LRC;
+    float *ubl = lds;                   // SR x SC window of xbar_u
+    float *psum = lds + SR * SC;        // [4 waves][nlr] partial sums of A xbar_u
+    const float *ub = FR(a.ub, t), *wb = FR(a.wb, t);
+
+    const int rq = tid & (TILE_R / 4 - 1), lc = tid / (TILE_R / 4);
+    const int r = r0 + 4 * rq, c = c0 + lc;
+    const bool active = r < g.Ny && c < g.Nx;
+    const int j = active ? r + g.Ny * c : 0;
+    const bool hasx = c < g.Nx - 1;
+
+    // own loads first; they stay in flight while the window is staged
+    float o1t[4], o1x[4], o1y[4], o2t[4], o2x[4], o2y[4], fvx[4], fvy[4];
+    float uc[4], ux[4], wc[4] = {0.f, 0.f, 0.f, 0.f}, wx[4] = {0.f, 0.f, 0.f, 0.f};
+    float ubelow = 0.f, wbelow = 0.f;
+    if (active) {
+        if (pex) { ld4(fvx, FR(a.vx, t) + j); ld4(fvy, FR(a.vy, t) + j); }
+        ld4(uc, ub + j);
+        if (hasx) ld4(ux, ub + j + g.Ny);
+        if (r + 4 < g.Ny) ubelow = ub[j + 4];
+        if (MODEL == MODEL_IC) {
+            ld4(wc, wb + j);
+            if (hasx) ld4(wx, wb + j + g.Ny);
+            if (r + 4 < g.Ny) wbelow = wb[j + 4];
+        }
+        if (MODE == MODE_UPDATE) {
+            ld4(o1t, FR(a.g1t, t) + j); ld4(o1x, FR(a.g1x, t) + j); ld4(o1y, FR(a.g1y, t) + j);
+            if (MODEL == MODEL_IC) { ld4(o2t, FR(a.g2t, t) + j); ld4(o2x, FR(a.g2x, t) + j); ld4(o2y, FR(a.g2y, t) + j); }
+        }
+    }
+
+    // stage the xbar_u window, replicate border (helpers/RepConvMtx.m:23-32)
+    if (MODE != MODE_STEPS) {
+        const float inv_sr = 1.f / (float)SR;
+        for (int k = tid; k < SR * SC; k += MMC_THREADS) {
+            int kc = (int)(((float)k + 0.5f) * inv_sr);
+            int kr = k - kc * SR;
+            if (kr < 0) { --kc; kr += SR; }
+            if (kr >= SR) { ++kc; kr -= SR; }
+            const int rr = min(max(r0 + g.oy + kr, 0), g.Ny - 1);
+            const int cc = min(max(c0 + g.ox + kc, 0), g.Nx - 1);
+            ubl[k] = ub[rr + g.Ny * cc];
+        }
+    }
+
+    float part[2] = {0.f, 0.f};
+    if (active) {
+        const float *ubW = FR(a.ub, isIF ? t + 1 : t), *wbW = FR(a.wb, isIF ? t + 1 : t);   // warped frame
+        float k1t[4], k1x[4], k1y[4], k2t[4], k2x[4], k2y[4], sg1[4], sg2[4];
+        bool valid[4];
+        float idu[4], idw[4];
+        if (pex && !isIF) {   // identity block sits on the next frame
+            ld4(idu, FR(a.ub, t + 1) + j);
+            if (MODEL == MODEL_IC) ld4(idw, FR(a.wb, t + 1) + j);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool hasy = r + i < g.Ny - 1;
+            const float uy = i < 3 ? uc[i < 3 ? i + 1 : 3] : ubelow;
+            const float wy = i < 3 ? wc[i < 3 ? i + 1 : 3] : wbelow;
+            float tu = 0.f, tw = 0.f;
+            valid[i] = false;
+            if (pex) {
+                Taps tp = make_taps(g, r + i, c, fvx[i], fvy[i]);
+                valid[i] = tp.valid;
+                if (tp.valid) {
+                    tu = sample(tp, ubW) - (isIF ? uc[i] : idu[i]);
+                    if (MODEL == MODEL_IC) tw = sample(tp, wbW) - (isIF ? wc[i] : idw[i]);
+                }
+            }
+            float rs1, rs2 = 0.f;
+            if (MODEL == MODEL_IC) {
+                // K1 (u - w), K1 = [W/h ; kappa G]  (:490-491);  K2 w, K2 = [kappa W/h ; G]  (:492)
+                const float dc = uc[i] - wc[i];
+                k1t[i] = (tu - tw) * g.inv_h;
+                k1x[i] = hasx ? kap * ((ux[i] - wx[i]) - dc) : 0.f;
+                k1y[i] = hasy ? kap * ((uy - wy) - dc) : 0.f;
+                k2t[i] = kap * tw * g.inv_h;
+                k2x[i] = hasx ? wx[i] - wc[i] : 0.f;
+                k2y[i] = hasy ? wy - wc[i] : 0.f;
+                rs1 = fmaxf(valid[i] ? 4.f * g.inv_h : 0.f, fmaxf(hasx ? 4.f * kap : 0.f, hasy ? 4.f * kap : 0.f));
+                rs2 = fmaxf(valid[i] ? 2.f * kap * g.inv_h : 0.f, fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f));
+            } else {
+                k1t[i] = tu * g.inv_h;
+                k1x[i] = hasx ? ux[i] - uc[i] : 0.f;
+                k1y[i] = hasy ? uy - uc[i] : 0.f;
+                k2t[i] = k2x[i] = k2y[i] = 0.f;
+                if (MODEL == MODEL_K1) {
+                    rs1 = fmaxf(valid[i] ? 2.f * g.inv_h : 0.f, fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f));
+                } else {
+                    rs1 = valid[i] ? 2.f * g.inv_h : 0.f;
+                    rs2 = fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f);
+                }
+            }
+            sg1[i] = rs1 > 0.f ? 1.f / rs1 : 1.f;
+            sg2[i] = rs2 > 0.f ? 1.f / rs2 : 1.f;
+        }
+        float *g1t = FR(a.g1t, t) + j, *g1x = FR(a.g1x, t) + j, *g1y = FR(a.g1y, t) + j;
+        float *g2t = FR(a.g2t, t) + j, *g2x = FR(a.g2x, t) + j, *g2y = FR(a.g2y, t) + j;
+        if (MODE == MODE_RAW) {
+            st4(g1t, k1t); st4(g1x, k1x); st4(g1y, k1y);
+            if (MODEL == MODEL_IC) { st4(g2t, k2t); st4(g2x, k2x); st4(g2y, k2y); }
+        } else if (MODE == MODE_STEPS) {
+            st4(g1t, sg1);
+            st4(g2t, sg2);
+        } else if (MODE == MODE_ENERGY) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (MODEL == MODEL_IC)
+                    part[0] += g.radius1 * sqrtf(k1t[i] * k1t[i] + k1x[i] * k1x[i] + k1y[i] * k1y[i]) +
+                               g.radius2 * sqrtf(k2t[i] * k2t[i] + k2x[i] * k2x[i] + k2y[i] * k2y[i]);
+                else if (MODEL == MODEL_K1)
+                    part[0] += g.radius1 * sqrtf(k1t[i] * k1t[i] + k1x[i] * k1x[i] + k1y[i] * k1y[i]);
+                else
+                    part[0] += g.radius1 * fabsf(k1t[i]) + g.radius2 * sqrtf(k1x[i] * k1x[i] + k1y[i] * k1y[i]);
+            }
+        } else {
+            float n1t[4], n1x[4], n1y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (MODEL == MODEL_ADD) {
+                    // |g1| <= alpha (:532) on the temporal row, ||(gx,gy)|| <= alpha (:533)
+                    n1t[i] = valid[i] ? fminf(fmaxf(o1t[i] + sg1[i] * k1t[i], -g.radius1), g.radius1) : 0.f;
+                    n1x[i] = o1x[i] + sg2[i] * k1x[i];
+                    n1y[i] = o1y[i] + sg2[i] * k1y[i];
+                    const float nrm = sqrtf(n1x[i] * n1x[i] + n1y[i] * n1y[i]);
+                    if (nrm > g.radius2) { const float sc = g.radius2 / nrm; n1x[i] *= sc; n1y[i] *= sc; }
+                } else {
+                    // ||(gt,gx,gy)||_2 <= radius (:497, :513)
+                    n1t[i] = valid[i] ? o1t[i] + sg1[i] * k1t[i] : 0.f;
+                    n1x[i] = o1x[i] + sg1[i] * k1x[i];
+                    n1y[i] = o1y[i] + sg1[i] * k1y[i];
+                    const float nrm = sqrtf(n1t[i] * n1t[i] + n1x[i] * n1x[i] + n1y[i] * n1y[i]);
+                    if (nrm > g.radius1) { const float sc = g.radius1 / nrm; n1t[i] *= sc; n1x[i] *= sc; n1y[i] *= sc; }
+                }
+                if (REDUCE) {
+                    part[0] += (n1t[i] - o1t[i]) * (n1t[i] - o1t[i]) + (n1x[i] - o1x[i]) * (n1x[i] - o1x[i]) +
+                               (n1y[i] - o1y[i]) * (n1y[i] - o1y[i]);
+                    part[1] += n1t[i] * n1t[i] + n1x[i] * n1x[i] + n1y[i] * n1y[i];
+                }
+            }
+            st4(g1t, n1t); st4(g1x, n1x); st4(g1y, n1y);
+            if (MODEL == MODEL_IC) {
+                float n2t[4], n2x[4], n2y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    n2t[i] = valid[i] ? o2t[i] + sg2[i] * k2t[i] : 0.f;
+                    n2x[i] = o2x[i] + sg2[i] * k2x[i];
+                    n2y[i] = o2y[i] + sg2[i] * k2y[i];
+                    const float nrm = sqrtf(n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i]);
+                    if (nrm > g.radius2) { const float sc = g.radius2 / nrm; n2t[i] *= sc; n2x[i] *= sc; n2y[i] *= sc; }
+                    if (REDUCE) {
+                        part[0] += (n2t[i] - o2t[i]) * (n2t[i] - o2t[i]) + (n2x[i] - o2x[i]) * (n2x[i] - o2x[i]) +
+                                   (n2y[i] - o2y[i]) * (n2y[i] - o2y[i]);
+                        part[1] += n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i];
+                    }
+                }
+                st4(g2t, n2t); st4(g2x, n2x); st4(g2y, n2y);
+            }
+        }
+    }
+
+    // ---- data term: p <- clamp(p + s (A xbar_u - f), -1, 1)   (:496) --------
+    float epart = 0.f;
+    if (MODE != MODE_STEPS) {
+        __syncthreads();
+        const int wv = tid >> 6, lane = tid & 63;
+        for (int lp = lane; lp < nlr; lp += 64) {
+            const int Rl = lp % LRR, Cl = lp / LRR;
+            float s = 0.f;
+            for (int nn = wv; nn < g.CW; nn += MMC_THREADS / 64) {
+                const float *col = ubl + f * Rl + SR * (f * Cl + nn);
+                const float *ck = a.cker + g.CH * nn;
+                for (int mm = 0; mm < g.CH; ++mm) s += ck[mm] * col[mm];
+            }
+            psum[wv * nlr + lp] = s;
+        }
+        __syncthreads();
+    }
+    for (int lp = tid; lp < nlr; lp += MMC_THREADS) {
+        const int Rl = lp % LRR, Cl = lp / LRR;
+        const int R = r0 / f + Rl, C = c0 / f + Cl;
+        if (R >= g.ny || C >= g.nx) continue;
+        const int i = R + g.ny * C;
+        const size_t o = (size_t)t * g.n + i;
+        const float sg = a.sigp[i];
+        if (MODE == MODE_STEPS) { a.p[o] = sg; continue; }
+        const float acc = psum[lp] + psum[nlr + lp] + psum[2 * nlr + lp] + psum[3 * nlr + lp];
+        if (MODE == MODE_RAW) {
+            a.p[o] = acc;
+        } else if (MODE == MODE_ENERGY) {
+            epart += fabsf(acc - a.f[o]);
+        } else {
+            const float po = a.p[o];
+            const float pn = fminf(fmaxf(po + sg * (acc - a.f[o]), -1.f), 1.f);
+            a.p[o] = pn;
+            if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; }
+        }
+    }
+    if (MODE == MODE_ENERGY) { float e[2] = {part[0], epart}; block_accumulate<2>(e, a.sums, 4); }
+    else if (REDUCE) block_accumulate<2>(part, a.sums, 2);
+}
+
+// --------------------------------------------------------------------------
 // one-off kernels
 // --------------------------------------------------------------------------
 
@@ -857,10 +1082,36 @@ static void launch_dual_m(const Geom &g, const Arrays &a, int t0, int nf, int mo
     else hipLaunchKernelGGL((k_dual<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
 }
 
+template <int MODEL, int F>
+static void launch_dual4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+    dim3 grid(g.ntiles, nf), block(MMC_THREADS);
+    const int f = g.f;
+    const size_t lds = (size_t)((TILE_R + g.CH - f) * (TILE_C + g.CW - f) + 4 * (TILE_R / f) * (TILE_C / f)) * sizeof(float);
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0);
+    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F>), grid, block, lds, s, g, a, t0);
+    else if (reduce) hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0);
+    else hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0);
+}
+
+template <int F>
+static void launch_dual4(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+    if (g.model == MODEL_IC) launch_dual4_m<MODEL_IC, F>(g, a, t0, nf, mode, reduce, s);
+    else if (g.model == MODEL_K1) launch_dual4_m<MODEL_K1, F>(g, a, t0, nf, mode, reduce, s);
+    else launch_dual4_m<MODEL_ADD, F>(g, a, t0, nf, mode, reduce, s);
+}
+
 hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s,
                            hipEvent_t mid) {
     if (t1 <= t0) return hipSuccess;
     const int nf = t1 - t0;
+    if (g.Ny % 4 == 0 && TILE_R % g.f == 0 && TILE_C % g.f == 0 && !(g.dbg & 16)) {
+        // fused row-quad kernel: regulariser duals and data-term dual in one launch
+        if (g.f == 4) launch_dual4<4>(g, a, t0, nf, mode, reduce, s);
+        else launch_dual4<0>(g, a, t0, nf, mode, reduce, s);
+        if (mid) (void)hipEventRecord(mid, s);
+        return hipGetLastError();
+    }
     if (g.model == MODEL_IC) launch_dual_m<MODEL_IC>(g, a, t0, nf, mode, reduce, s);
     else if (g.model == MODEL_K1) launch_dual_m<MODEL_K1>(g, a, t0, nf, mode, reduce, s);
     else launch_dual_m<MODEL_ADD>(g, a, t0, nf, mode, reduce, s);
