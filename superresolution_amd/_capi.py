@@ -96,7 +96,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("MMC_HIP_LIB") or LIB_PATH
     if not os.path.exists(path):
         raise ImportError("libmmc_hip.so not found at %s -- build it with "
                           "`python -m superresolution_amd.build` (there is no CPU fallback)" % path)

@@ -11,7 +11,14 @@ enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3 };
 // One workgroup of 256 threads owns a TILE_R x TILE_C pixel tile of one frame.
 // Rows are the contiguous axis (column-major frames), so one 64-lane wave
 // covers 64 consecutive rows of a column.
-enum { TILE_R = 64, TILE_C = 16, MMC_THREADS = 256 };
+#ifndef MMC_TILE_R
+#define MMC_TILE_R 64
+#endif
+#ifndef MMC_TILE_C
+#define MMC_TILE_C 16
+#endif
+enum { TILE_R = MMC_TILE_R, TILE_C = MMC_TILE_C, MMC_THREADS = 256 };
+static_assert(TILE_R * TILE_C == 4 * MMC_THREADS && (TILE_R & (TILE_R - 1)) == 0, "tile must hold one row quad per thread");
 enum { MMC_MAX_CK = 24 };      // max side of the composite (sampling * blur) kernel
 enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
 enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device

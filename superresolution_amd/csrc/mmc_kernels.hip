@@ -115,9 +115,31 @@ __device__ __forceinline__ void block_accumulate(float (&v)[NV], double *sums, i
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < MMC_THREADS / 64; ++k) s += red[threadIdx.x][k];
-        int slot = (blockIdx.x + blockIdx.y * 7) & (MMC_SUM_SLOTS - 1);
+        int slot = (blockIdx.x + blockIdx.y * 7) & (MMC_SUM_SLOTS - 1);   // spread the atomics
         atomicAdd(&sums[(size_t)(first + threadIdx.x) * MMC_SUM_SLOTS + slot], (double)s);
     }
+}
+
+
+// Work item (tile, frame) of a workgroup in the 1-D grids of the row-quad
+// kernels.  Workgroups b and b+8 are observed to share an XCD (and its L2).
+// Column tiles are not aligned to 128-byte lines (a column is Ny*4 bytes), so
+// vertically adjacent tiles share cache lines; residue class b%8 therefore owns
+// a contiguous range of the (row-fastest) tile index and walks it in order,
+// frame after frame, so that those shared lines are fetched once per L2 and
+// DRAM pages are visited in address order.  Measured on a 9-read/4-write float4
+// streaming kernel over 1080-row frames: 5.4 TB/s against 4.3 TB/s for
+// round-robin tiles.  Placement only affects speed; surplus workgroups exit.
+__device__ __forceinline__ bool decode_block(const Geom &g, int nf, int &tile, int &trel) {
+    const int b = blockIdx.x;
+    if (g.dbg & 32) { tile = b % g.ntiles; trel = b / g.ntiles; return trel < nf; }
+    const int x = b & 7, s = b >> 3;
+    const int q = (g.ntiles + 7) >> 3;
+    const int lo = x * q, cnt = min(q, g.ntiles - lo);
+    if (cnt <= 0 || s >= cnt * nf) return false;
+    trel = s / cnt;
+    tile = lo + (s - trel * cnt);
+    return true;
 }
 
 // (A' p)(r,c): gather form of the adjoint of D*B with the replicate border of
@@ -308,7 +330,7 @@ __device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
 }
 
 template <int MODEL, int MODE, bool REDUCE, int F>
-__global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t0) {
+__global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     fx64 *acc1 = reinterpret_cast<fx64 *>(lds);
     fx64 *acc2 = acc1 + TILE_R * TILE_C;
@@ -316,8 +338,9 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     float *pl = ckp + g.MP * g.NP;
     const int f = F > 0 ? F : g.f;
     const int tid = threadIdx.x;
-    const int t = t0 + blockIdx.y;
-    const int tile = blockIdx.x;
+    int tile, trel;
+    if (!decode_block(g, nf, tile, trel)) return;
+    const int t = t0 + trel;
     const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
     const int r0 = tr * TILE_R, c0 = tc * TILE_C;
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
@@ -733,12 +756,13 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0
 // low-res dual p of the tile from it: wave w sums the composite-kernel columns
 // n = w, w+4, ... for every low-res pixel, the four partial sums meet in LDS.
 template <int MODEL, int MODE, bool REDUCE, int F>
-__global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0) {
+__global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     const int f = F > 0 ? F : g.f;
     const int tid = threadIdx.x;
-    const int t = t0 + blockIdx.y;
-    const int tile = blockIdx.x;
+    int tile, trel;
+    if (!decode_block(g, nf, tile, trel)) return;
+    const int t = t0 + trel;
     const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
     const int r0 = tr * TILE_R, c0 = tc * TILE_C;
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
@@ -777,7 +801,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0)
     }
 
     // stage the xbar_u window, replicate border (helpers/RepConvMtx.m:23-32)
-    if (MODE != MODE_STEPS) {
+    if (MODE != MODE_STEPS && !(g.dbg & 512)) {
         const float inv_sr = 1.f / (float)SR;
         for (int k = tid; k < SR * SC; k += MMC_THREADS) {
             int kc = (int)(((float)k + 0.5f) * inv_sr);
@@ -807,7 +831,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0)
             const float wy = i < 3 ? wc[i < 3 ? i + 1 : 3] : wbelow;
             float tu = 0.f, tw = 0.f;
             valid[i] = false;
-            if (pex) {
+            if (pex && !(g.dbg & 256)) {
                 Taps tp = make_taps(g, r + i, c, fvx[i], fvy[i]);
                 valid[i] = tp.valid;
                 if (tp.valid) {
@@ -909,7 +933,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0)
 
     // ---- data term: p <- clamp(p + s (A xbar_u - f), -1, 1)   (:496) --------
     float epart = 0.f;
-    if (MODE != MODE_STEPS) {
+    if (MODE != MODE_STEPS && !(g.dbg & 512)) {
         __syncthreads();
         const int wv = tid >> 6, lane = tid & 63;
         for (int lp = lane; lp < nlr; lp += 64) {
@@ -1044,12 +1068,12 @@ static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int 
 
 template <int MODEL, int F>
 static void launch_primal4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
-    dim3 grid(g.ntiles, nf), block(MMC_THREADS);
+    dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const size_t lds = (size_t)(4 * TILE_R * TILE_C + g.MP * g.NP + g.PR * g.PC) * sizeof(float);
-    if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0);
-    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0);
-    else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0);
-    else hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0);
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
+    else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0, nf);
+    else hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0, nf);
 }
 
 template <int F>
@@ -1084,14 +1108,14 @@ static void launch_dual_m(const Geom &g, const Arrays &a, int t0, int nf, int mo
 
 template <int MODEL, int F>
 static void launch_dual4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
-    dim3 grid(g.ntiles, nf), block(MMC_THREADS);
+    dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const int f = g.f;
     const size_t lds = (size_t)((TILE_R + g.CH - f) * (TILE_C + g.CW - f) + 4 * (TILE_R / f) * (TILE_C / f)) * sizeof(float);
-    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0);
-    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0);
-    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F>), grid, block, lds, s, g, a, t0);
-    else if (reduce) hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0);
-    else hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0);
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F>), grid, block, lds, s, g, a, t0, nf);
+    else if (reduce) hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0, nf);
+    else hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0, nf);
 }
 
 template <int F>
