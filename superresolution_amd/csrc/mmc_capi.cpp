@@ -28,6 +28,7 @@ struct mmc_handle {
     bool have_f = false, have_flow = false, have_state = false, inited = false, have_h = false;
     float h = 1.f;
     std::vector<void *> allocs;
+    unsigned long long *scratch = nullptr;   // one frame of 64-bit words for mmc_init
     std::string err;
     bool profiling = false;
     std::vector<hipEvent_t> events;       // 4 per profiled iteration
@@ -161,6 +162,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.ckp, (size_t)(MMC_MAX_CK + p->factor) * (MMC_MAX_CK + p->factor))) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.bbox, (size_t)(h->L + 1) * g.ntiles * 4)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &h->scratch, (size_t)g.N)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)) != MMC_OK) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MMC_ERR_HIP); }
     *out = h;
@@ -385,14 +387,13 @@ extern "C" int mmc_init(mmc_handle *h) {
     if ((rc = build_data_operator(h))) return rc;
     const Geom &g = h->g;
     Arrays &a = h->a;
-    HIPCHK(h, hipMemsetAsync(a.cW, 0, frame_slots(h) * (size_t)g.N * sizeof(float), h->stream));
     {
         std::vector<int> bb((size_t)(h->L + 1) * g.ntiles * 4);
         for (size_t i = 0; i < bb.size(); i += 4) { bb[i] = INT_MAX; bb[i + 1] = -1; bb[i + 2] = INT_MAX; bb[i + 3] = -1; }
         HIPCHK(h, hipMemcpyAsync(a.bbox, bb.data(), bb.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    HIPCHK(h, mmc_launch_init_warp(g, a, h->stream));
+    HIPCHK(h, mmc_launch_init_warp(g, a, h->scratch, h->stream));
     HIPCHK(h, mmc_launch_sanitize(g, a, h->stream));
     if (!h->have_h) {
         // MultiframeMotionCoupling.m:431-437, from this block's own sums

@@ -977,37 +977,44 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
 // --------------------------------------------------------------------------
 
 // Column abs-sums of the motion-coupling operator and, per target tile, the
-// bounding box of the source pixels whose taps land in it.
-__global__ __launch_bounds__(MMC_THREADS) void k_init_warp(Geom g, Arrays a) {
-    const int q = (int)blockIdx.y - 1;
-    if (!pair_exists(g, q)) return;
+// bounding box of the source pixels whose taps land in it.  Pass 1 (per pair q
+// whose warp samples frame wf): tap weights are summed per target pixel in
+// 64-bit fixed point (order-independent) and the tile boxes are widened.
+__global__ __launch_bounds__(MMC_THREADS) void k_init_scatter(Geom g, Arrays a, int q, fx64 *tmp) {
     const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
     if (j >= g.N) return;
     const int r = j % g.Ny, c = j / g.Ny;
     Taps tp = make_taps(g, r, c, FR(a.vx, q)[j], FR(a.vy, q)[j]);
     if (!tp.valid) return;
-    const bool isIF = pair_is_IF(g, q);
-    const int wf = isIF ? q + 1 : q, idf = isIF ? q : q + 1;
-    if (wf >= 0 && wf < g.L) {
-        float *cW = FR(a.cW, wf);
-        atomicAdd(&cW[tp.i00], tp.w00);
-        atomicAdd(&cW[tp.i10], tp.w10);
-        atomicAdd(&cW[tp.i01], tp.w01);
-        atomicAdd(&cW[tp.i11], tp.w11);
-        int *bb = a.bbox + (size_t)(q + 1) * g.ntiles * 4;
-        const int tr0 = tp.r0 / TILE_R, tr1 = tp.r1 / TILE_R, tc0 = tp.c0 / TILE_C, tc1 = tp.c1 / TILE_C;
+    atomicAdd(&tmp[tp.i00], to_fx(tp.w00));
+    atomicAdd(&tmp[tp.i10], to_fx(tp.w10));
+    atomicAdd(&tmp[tp.i01], to_fx(tp.w01));
+    atomicAdd(&tmp[tp.i11], to_fx(tp.w11));
+    int *bb = a.bbox + (size_t)(q + 1) * g.ntiles * 4;
+    const int tr0 = tp.r0 / TILE_R, tr1 = tp.r1 / TILE_R, tc0 = tp.c0 / TILE_C, tc1 = tp.c1 / TILE_C;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ttr = (k & 1) ? tr1 : tr0, ttc = (k & 2) ? tc1 : tc0;
-            if (k == 1 && tr1 == tr0) continue;
-            if (k == 2 && tc1 == tc0) continue;
-            if (k == 3 && (tr1 == tr0 || tc1 == tc0)) continue;
-            int *b = bb + (size_t)(ttr + g.tiles_r * ttc) * 4;
-            atomicMin(&b[0], r); atomicMax(&b[1], r);
-            atomicMin(&b[2], c); atomicMax(&b[3], c);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int ttr = (k & 1) ? tr1 : tr0, ttc = (k & 2) ? tc1 : tc0;
+        if (k == 1 && tr1 == tr0) continue;
+        if (k == 2 && tc1 == tc0) continue;
+        if (k == 3 && (tr1 == tr0 || tc1 == tc0)) continue;
+        int *b = bb + (size_t)(ttr + g.tiles_r * ttc) * 4;
+        atomicMin(&b[0], r); atomicMax(&b[1], r);
+        atomicMin(&b[2], c); atomicMax(&b[3], c);
     }
-    if (idf >= 0 && idf < g.L) atomicAdd(&FR(a.cW, idf)[j], 1.f);
+}
+
+// Pass 2 for frame t: cW = scattered weights + 1 for every unmasked row whose
+// -Id entry sits on this frame (pair t if 'I-F', pair t-1 if 'F-I').
+__global__ __launch_bounds__(MMC_THREADS) void k_init_finalize(Geom g, Arrays a, int t, const fx64 *tmp) {
+    const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    const int r = j % g.Ny, c = j / g.Ny;
+    float s = from_fx(tmp[j]);
+    if (pair_exists(g, t) && pair_is_IF(g, t) && make_taps(g, r, c, FR(a.vx, t)[j], FR(a.vy, t)[j]).valid) s += 1.f;
+    if (pair_exists(g, t - 1) && !pair_is_IF(g, t - 1) &&
+        make_taps(g, r, c, FR(a.vx, t - 1)[j], FR(a.vy, t - 1)[j]).valid) s += 1.f;
+    FR(a.cW, t)[j] = s;
 }
 
 // Temporal duals of masked rows are identically zero; enforce it after a flow
@@ -1150,9 +1157,18 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
     return hipGetLastError();
 }
 
-hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, hipStream_t s) {
-    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS, g.L + 1), block(MMC_THREADS);
-    hipLaunchKernelGGL(k_init_warp, grid, block, 0, s, g, a);
+hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *scratch, hipStream_t s) {
+    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS), block(MMC_THREADS);
+    fx64 *tmp = static_cast<fx64 *>(scratch);
+    auto exists = [&](int q) { int gq = g.frame_begin + q; return q >= -1 && q <= g.L - 1 && gq >= 0 && gq <= g.nc_global - 2; };
+    auto is_if = [&](int q) { return g.dir == 1 ? true : g.dir == 0 ? false : ((g.frame_begin + q) & 1) == 0; };
+    for (int t = 0; t < g.L; ++t) {
+        hipError_t e = hipMemsetAsync(tmp, 0, (size_t)g.N * sizeof(fx64), s);
+        if (e != hipSuccess) return e;
+        if (exists(t - 1) && is_if(t - 1)) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, t - 1, tmp);
+        if (exists(t) && !is_if(t)) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, t, tmp);
+        hipLaunchKernelGGL(k_init_finalize, grid, block, 0, s, g, a, t, tmp);
+    }
     return hipGetLastError();
 }
 

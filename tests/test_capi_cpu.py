@@ -1,0 +1,91 @@
+"""CPU checks of the drop-in boundary: libmmc_hip.so loads, exports every symbol
+that include/mmc_hip.h declares, and rejects bad parameters the way
+MultiframeMotionCoupling.init does -- without any compute call (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from superresolution_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mmc_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmc_[a-z_A-Z0-9]+)\s*\(", text)) - {"mmc_progress_cb"})
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load_library()
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libmmc_hip.so does not export %s" % n
+    assert sorted(_capi.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.mmc_abi_version() == _capi.MMC_ABI_VERSION
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary must be consumable from C (MEX gateways are C or C++)."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "mmc_hip.h"\nint main(void){ mmc_params p; p.size = sizeof(p); return (int)p.size == 0; }\n')
+    import subprocess
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                    "-o", str(tmp_path / "t.o")], check=True)
+
+
+def _params(**kw):
+    p = _capi.mmc_params()
+    p.size = C.sizeof(_capi.mmc_params)
+    p.version = _capi.MMC_ABI_VERSION
+    p.ny, p.nx, p.factor, p.nc_global, p.frame_begin, p.frame_end = 8, 8, 4, 3, 0, 3
+    p.alpha, p.kappa, p.h = 0.01, 0.25, 0.0
+    p.flow_direction, p.sampling, p.device = 1, 0, 0
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+@pytest.mark.parametrize("kw,status,text", [
+    ({"factor": 0}, -1, "Input must be > 0"),                 # MultiframeMotionCoupling.m:228, :1057-1058
+    ({"alpha": -1.0}, -1, "Input must be > 0"),
+    ({"kappa": 0.0}, -1, "Input must be > 0"),
+    ({"flow_direction": 7}, -1, "Invalid flow direction"),
+    ({"frame_end": 5}, -1, "frame block"),
+    ({"sampling": 9}, -4, "interpMethod"),
+    ({"factor": 2}, -4, "factor 4"),                         # 'average' is a block mean only at factor 4
+    ({"size": 4}, -1, "size/version"),
+])
+def test_create_rejects_bad_parameters(kw, status, text):
+    lib = _capi.load_library()
+    h = C.c_void_p()
+    p = _params(**kw)
+    rc = lib.mmc_create(C.byref(p), C.byref(h))
+    assert rc == status and not h.value
+    assert text in lib.mmc_last_error(None).decode()
+
+
+def test_create_without_gpu_reports_no_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _capi.load_library()
+    h = C.c_void_p()
+    p = _params()
+    rc = lib.mmc_create(C.byref(p), C.byref(h))
+    assert rc == -5 and "no HIP device" in lib.mmc_last_error(None).decode()
+    with pytest.raises(_capi.MMCError):
+        from superresolution_amd.solver import FrameBlockSolver
+        FrameBlockSolver(8, 8, 4, 3)          # the product path fails loudly, no CPU fallback
+
+
+def test_null_handle_is_rejected():
+    lib = _capi.load_library()
+    assert lib.mmc_init(None) == -1
+    assert lib.mmc_solve(None, 1, 0.0, 0, None, _capi.PROGRESS_CB(), None) == -1
+    assert lib.mmc_destroy(None) == 0
