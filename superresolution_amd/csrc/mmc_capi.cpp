@@ -162,6 +162,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.ckp, (size_t)(MMC_MAX_CK + p->factor) * (MMC_MAX_CK + p->factor))) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.bbox, (size_t)(h->L + 1) * g.ntiles * 4)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.tbox, (size_t)h->L * g.ntiles * 4)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &h->scratch, (size_t)g.N)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)) != MMC_OK) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MMC_ERR_HIP); }

@@ -20,6 +20,7 @@ enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3 };
 enum { TILE_R = MMC_TILE_R, TILE_C = MMC_TILE_C, MMC_THREADS = 256 };
 static_assert(TILE_R * TILE_C == 4 * MMC_THREADS && (TILE_R & (TILE_R - 1)) == 0, "tile must hold one row quad per thread");
 enum { MMC_MAX_CK = 24 };      // max side of the composite (sampling * blur) kernel
+enum { MMC_WARP_MAX = 2304 }; // floats of the warped frame a tile may stage in LDS per plane
 enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
 enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device
 
@@ -56,7 +57,8 @@ struct Arrays {
     float *sigp;               // 1 / row abs-sum of D*B, n
     float *cker;               // composite kernel, CH x CW column-major
     float *ckp;                // the same, zero-padded to MP x NP
-    int *bbox;                 // [(L+1) pair slots][ntiles][4] = rmin,rmax,cmin,cmax
+    int *bbox;                 // [(L+1) pair slots][ntiles][4] = rmin,rmax,cmin,cmax of the SOURCES of a tile
+    int *tbox;                 // [L pair slots][ntiles][4] = rows/cols of the warped frame a tile's TAPS touch
     double *sums;              // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]
 };
 

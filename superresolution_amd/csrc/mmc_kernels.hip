@@ -93,6 +93,13 @@ __device__ __forceinline__ float from_fx(fx64 v) {
 }
 __device__ __forceinline__ void fx_add(fx64 *acc, float x) { atomicAdd(acc, to_fx(x)); }
 
+// The same interpolation from an LDS copy of the rows [rlo, rlo+WR) x columns [clo, ...) of the frame.
+__device__ __forceinline__ float sample_lds(const Taps &t, const float *img, int rlo, int clo, int WR) {
+    const int i0 = (t.r0 - rlo) + WR * (t.c0 - clo);
+    const int dr = t.r1 - t.r0, dc = (t.c1 - t.c0) * WR;
+    return t.w00 * img[i0] + t.w10 * img[i0 + dr] + t.w01 * img[i0 + dc] + t.w11 * img[i0 + dr + dc];
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     fx64 *acc1 = reinterpret_cast<fx64 *>(lds);
     fx64 *acc2 = acc1 + TILE_R * TILE_C;
     float *ckp = lds + 4 * TILE_R * TILE_C;
-    float *pl = ckp + g.MP * g.NP;
+    float *pl = ckp + ((g.MP * g.NP + 3) & ~3);
     const int f = F > 0 ? F : g.f;
     const int tid = threadIdx.x;
     int tile, trel;
@@ -772,7 +779,25 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     const int LRR = TILE_R / f, LRC = TILE_C / f, nlr = LRR * LRC;
     float *ubl = lds;                   // SR x SC window of xbar_u
     float *psum = lds + SR * SC;        // [4 waves][nlr] partial sums of A xbar_u
+    float *wu = lds + ((SR * SC + 4 * nlr + 3) & ~3);   // tap region of the warped frame, xbar_u
+    float *ww = wu + MMC_WARP_MAX;                      // ... and xbar_w
     const float *ub = FR(a.ub, t), *wb = FR(a.wb, t);
+    const float *ubW = FR(a.ub, isIF ? t + 1 : t), *wbW = FR(a.wb, isIF ? t + 1 : t);   // warped frame
+    // Rows/columns of the warped frame that this tile's taps touch (from mmc_init), rows widened
+    // to whole quads.  If the region fits, it is staged in LDS with 16-byte loads and the 4 taps
+    // per pixel are LDS reads; otherwise (violent flow) they are gathered from global memory.
+    int wrlo = 0, wclo = 0, WR = 0, WC = 0;
+    bool use_lds = false;
+    if (pex && MODE != MODE_STEPS && !(g.dbg & 1024)) {
+        const int *tb = a.tbox + ((size_t)t * g.ntiles + tile) * 4;
+        if (tb[1] >= tb[0]) {
+            wrlo = tb[0] & ~3;
+            wclo = tb[2];
+            WR = (tb[1] | 3) - wrlo + 1;
+            WC = tb[3] - wclo + 1;
+            use_lds = WR * WC <= MMC_WARP_MAX;
+        }
+    }
 
     const int rq = tid & (TILE_R / 4 - 1), lc = tid / (TILE_R / 4);
     const int r = r0 + 4 * rq, c = c0 + lc;
@@ -813,10 +838,24 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
             ubl[k] = ub[rr + g.Ny * cc];
         }
     }
+    if (use_lds) {
+        const int QR = WR >> 2, nq = QR * WC;
+        const float inv_qr = 1.f / (float)QR;
+        for (int k = tid; k < nq; k += MMC_THREADS) {
+            int kc = (int)(((float)k + 0.5f) * inv_qr);
+            int kr = k - kc * QR;
+            if (kr < 0) { --kc; kr += QR; }
+            if (kr >= QR) { ++kc; kr -= QR; }
+            const int src = wrlo + 4 * kr + g.Ny * (wclo + kc);
+            *reinterpret_cast<float4 *>(wu + 4 * kr + WR * kc) = *reinterpret_cast<const float4 *>(ubW + src);
+            if (MODEL == MODEL_IC)
+                *reinterpret_cast<float4 *>(ww + 4 * kr + WR * kc) = *reinterpret_cast<const float4 *>(wbW + src);
+        }
+    }
+    if (MODE != MODE_STEPS) __syncthreads();
 
     float part[2] = {0.f, 0.f};
     if (active) {
-        const float *ubW = FR(a.ub, isIF ? t + 1 : t), *wbW = FR(a.wb, isIF ? t + 1 : t);   // warped frame
         float k1t[4], k1x[4], k1y[4], k2t[4], k2x[4], k2y[4], sg1[4], sg2[4];
         bool valid[4];
         float idu[4], idw[4];
@@ -835,8 +874,13 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                 Taps tp = make_taps(g, r + i, c, fvx[i], fvy[i]);
                 valid[i] = tp.valid;
                 if (tp.valid) {
-                    tu = sample(tp, ubW) - (isIF ? uc[i] : idu[i]);
-                    if (MODEL == MODEL_IC) tw = sample(tp, wbW) - (isIF ? wc[i] : idw[i]);
+                    if (use_lds) {
+                        tu = sample_lds(tp, wu, wrlo, wclo, WR) - (isIF ? uc[i] : idu[i]);
+                        if (MODEL == MODEL_IC) tw = sample_lds(tp, ww, wrlo, wclo, WR) - (isIF ? wc[i] : idw[i]);
+                    } else {
+                        tu = sample(tp, ubW) - (isIF ? uc[i] : idu[i]);
+                        if (MODEL == MODEL_IC) tw = sample(tp, wbW) - (isIF ? wc[i] : idw[i]);
+                    }
                 }
             }
             float rs1, rs2 = 0.f;
@@ -934,7 +978,6 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     // ---- data term: p <- clamp(p + s (A xbar_u - f), -1, 1)   (:496) --------
     float epart = 0.f;
     if (MODE != MODE_STEPS && !(g.dbg & 512)) {
-        __syncthreads();
         const int wv = tid >> 6, lane = tid & 63;
         for (int lp = lane; lp < nlr; lp += 64) {
             const int Rl = lp % LRR, Cl = lp / LRR;
@@ -1017,6 +1060,28 @@ __global__ __launch_bounds__(MMC_THREADS) void k_init_finalize(Geom g, Arrays a,
     FR(a.cW, t)[j] = s;
 }
 
+// Per (pair, tile): rows and columns of the warped frame touched by the taps of the tile's pixels.
+__global__ __launch_bounds__(MMC_THREADS) void k_init_tapbox(Geom g, Arrays a) {
+    __shared__ int box[4];
+    const int t = blockIdx.y, tile = blockIdx.x;
+    if (threadIdx.x == 0) { box[0] = INT_MAX; box[1] = -1; box[2] = INT_MAX; box[3] = -1; }
+    __syncthreads();
+    if (pair_exists(g, t)) {
+        const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+        for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) {
+            const int r = tr * TILE_R + k % TILE_R, c = tc * TILE_C + k / TILE_R;
+            if (r >= g.Ny || c >= g.Nx) continue;
+            const int j = r + g.Ny * c;
+            Taps tp = make_taps(g, r, c, FR(a.vx, t)[j], FR(a.vy, t)[j]);
+            if (!tp.valid) continue;
+            atomicMin(&box[0], tp.r0); atomicMax(&box[1], tp.r1);
+            atomicMin(&box[2], tp.c0); atomicMax(&box[3], tp.c1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) a.tbox[((size_t)t * g.ntiles + tile) * 4 + threadIdx.x] = box[threadIdx.x];
+}
+
 // Temporal duals of masked rows are identically zero; enforce it after a flow
 // swap so that the primal sweep may subtract them without re-reading the mask.
 __global__ __launch_bounds__(MMC_THREADS) void k_sanitize(Geom g, Arrays a) {
@@ -1076,7 +1141,7 @@ static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int 
 template <int MODEL, int F>
 static void launch_primal4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
-    const size_t lds = (size_t)(4 * TILE_R * TILE_C + g.MP * g.NP + g.PR * g.PC) * sizeof(float);
+    const size_t lds = (size_t)(4 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0, nf);
@@ -1117,7 +1182,8 @@ template <int MODEL, int F>
 static void launch_dual4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const int f = g.f;
-    const size_t lds = (size_t)((TILE_R + g.CH - f) * (TILE_C + g.CW - f) + 4 * (TILE_R / f) * (TILE_C / f)) * sizeof(float);
+    const size_t lds = (size_t)((((TILE_R + g.CH - f) * (TILE_C + g.CW - f) + 4 * (TILE_R / f) * (TILE_C / f) + 3) & ~3) +
+                                2 * MMC_WARP_MAX) * sizeof(float);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F>), grid, block, lds, s, g, a, t0, nf);
@@ -1169,6 +1235,7 @@ hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *scratch, h
         if (exists(t) && !is_if(t)) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, t, tmp);
         hipLaunchKernelGGL(k_init_finalize, grid, block, 0, s, g, a, t, tmp);
     }
+    hipLaunchKernelGGL(k_init_tapbox, dim3(g.ntiles, g.L), block, 0, s, g, a);
     return hipGetLastError();
 }
 
