@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--lr", type=int, nargs=2, default=[270, 480], metavar=("ny", "nx"))
     ap.add_argument("--kappa", type=float, default=0.25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional rehearsal: ranks share the visible GPUs (use with --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -96,12 +99,20 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible")
+    if args.share_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend=args.backend)
+        # the library queues on torch's current stream so that torch orders kernels and transfers;
+        # a stream of our own, because the default stream's handle is 0 (= "library, make your own")
+        torch.cuda.set_stream(torch.cuda.Stream())
 
     ny, nx = args.lr
     L = args.frames_per_gpu
@@ -138,6 +149,7 @@ def main():
         s.h = sharding.sharded_h(s, dev)
         ex = sharding.HaloExchanger(sharding.halo_tensors(s), rank, world)
         sharding.solve_sharded(s, ex, args.warmup, 0.0, 0, dev)
+        s.set_profiling(True)
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -148,6 +160,15 @@ def main():
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+        # this rank's sweeps, HIP events on the library's stream; a sweep is two launches when the
+        # block waits for a ghost frame in between
+        sp = s.get_sweep_profile()
+        cp = 2 if (s.has_prev and L > 1) else 1
+        cd = 2 if (s.has_next and L > 1) else 1
+        it_p, it_d = sp["primal_calls"] / cp, sp["dual_calls"] / cd
+        if it_p >= 1 and it_d >= 1:
+            prof = {"primal_ms": sp["primal_ms"] / it_p, "dual_reg_ms": sp["dual_ms"] / it_d, "dual_data_ms": 0.0,
+                    "iterations": int(min(it_p, it_d))}
     assert st["iterations"] == args.steps
 
     if rank == 0:

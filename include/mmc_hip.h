@@ -190,6 +190,11 @@ int mmc_sync(mmc_handle *h);
  * iterations averaged. */
 int mmc_set_profiling(mmc_handle *h, int enable);
 int mmc_get_profile(mmc_handle *h, double out_ms[3], int *iterations);
+/* The same for a block driven through mmc_sweep_primal / mmc_sweep_dual: summed
+ * duration in milliseconds and number of the timed calls (at most the first
+ * 4096 since mmc_set_profiling), [0] primal sweeps, [1] dual sweeps.
+ * Synchronises the stream.  No counterpart in the reference. */
+int mmc_get_sweep_profile(mmc_handle *h, double total_ms[2], int calls[2]);
 
 /* Result extraction, MultiframeMotionCoupling.m:983-986: u and w of the local
  * frames (w may be NULL). */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "mmc_sync": (C.c_int, [_H]),
     "mmc_set_profiling": (C.c_int, [_H, C.c_int]),
     "mmc_get_profile": (C.c_int, [_H, _dp, C.POINTER(C.c_int)]),
+    "mmc_get_sweep_profile": (C.c_int, [_H, _dp, C.POINTER(C.c_int)]),
     "mmc_get_state": (C.c_int, [_H, _fp, _fp]),
     "mmc_energy": (C.c_int, [_H, _dp]),
     "mmc_debug_apply_K": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),

@@ -34,6 +34,10 @@ struct mmc_handle {
     std::vector<hipEvent_t> events;       // 4 per profiled iteration
     double prof_ms[3] = {0, 0, 0};
     int prof_iters = 0;
+    // sweep-level API: (kind, start, stop) per timed launch group, kind 0 = primal, 1 = dual
+    std::vector<hipEvent_t> sweep_events;
+    std::vector<int> sweep_kinds;
+    size_t sweep_used = 0;
 };
 
 enum { PROF_MAX_ITERS = 512 };
@@ -176,6 +180,7 @@ extern "C" int mmc_destroy(mmc_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     for (hipEvent_t e : h->events) hipEventDestroy(e);
+    for (hipEvent_t e : h->sweep_events) hipEventDestroy(e);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return MMC_OK;
@@ -422,19 +427,68 @@ static int check_range(mmc_handle *h, int t0, int t1) {
     return MMC_OK;
 }
 
+enum { SWEEP_PROF_MAX = 4096 };
+
+// Event pair around one sweep call when profiling is on (bounded pool, first calls only).
+static int sweep_prof_begin(mmc_handle *h, int kind, hipEvent_t **ev) {
+    *ev = nullptr;
+    if (!h->profiling || h->sweep_used >= SWEEP_PROF_MAX) return MMC_OK;
+    if (h->sweep_events.size() < 2 * (h->sweep_used + 1)) {
+        hipEvent_t e0, e1;
+        HIPCHK(h, hipEventCreate(&e0));
+        HIPCHK(h, hipEventCreate(&e1));
+        h->sweep_events.push_back(e0);
+        h->sweep_events.push_back(e1);
+        h->sweep_kinds.push_back(kind);
+    }
+    h->sweep_kinds[h->sweep_used] = kind;
+    *ev = &h->sweep_events[2 * h->sweep_used];
+    HIPCHK(h, hipEventRecord((*ev)[0], h->stream));
+    return MMC_OK;
+}
+
+static int sweep_prof_end(mmc_handle *h, hipEvent_t *ev) {
+    if (!ev) return MMC_OK;
+    HIPCHK(h, hipEventRecord(ev[1], h->stream));
+    h->sweep_used++;
+    return MMC_OK;
+}
+
 extern "C" int mmc_sweep_primal(mmc_handle *h, int t0, int t1, int reduce) {
     REQUIRE_HANDLE(h);
     int rc = check_range(h, t0, t1); if (rc) return rc;
     if ((rc = use_device(h))) return rc;
+    if (t1 == t0) return MMC_OK;
+    hipEvent_t *ev;
+    if ((rc = sweep_prof_begin(h, 0, &ev))) return rc;
     HIPCHK(h, mmc_launch_primal(h->g, h->a, t0, t1, MODE_UPDATE, reduce != 0, h->stream));
-    return MMC_OK;
+    return sweep_prof_end(h, ev);
 }
 
 extern "C" int mmc_sweep_dual(mmc_handle *h, int t0, int t1, int reduce) {
     REQUIRE_HANDLE(h);
     int rc = check_range(h, t0, t1); if (rc) return rc;
     if ((rc = use_device(h))) return rc;
+    if (t1 == t0) return MMC_OK;
+    hipEvent_t *ev;
+    if ((rc = sweep_prof_begin(h, 1, &ev))) return rc;
     HIPCHK(h, mmc_launch_dual(h->g, h->a, t0, t1, MODE_UPDATE, reduce != 0, h->stream));
+    return sweep_prof_end(h, ev);
+}
+
+extern "C" int mmc_get_sweep_profile(mmc_handle *h, double total_ms[2], int calls[2]) {
+    REQUIRE_HANDLE(h);
+    if (!total_ms || !calls) return fail(h, MMC_ERR_INVALID_ARG, "mmc_get_sweep_profile: null output");
+    int rc = use_device(h); if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    total_ms[0] = total_ms[1] = 0.0;
+    calls[0] = calls[1] = 0;
+    for (size_t i = 0; i < h->sweep_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->sweep_events[2 * i], h->sweep_events[2 * i + 1]));
+        total_ms[h->sweep_kinds[i]] += ms;
+        calls[h->sweep_kinds[i]]++;
+    }
     return MMC_OK;
 }
 
@@ -554,6 +608,7 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
 extern "C" int mmc_set_profiling(mmc_handle *h, int enable) {
     REQUIRE_HANDLE(h);
     h->profiling = enable != 0;
+    h->sweep_used = 0;
     return MMC_OK;
 }
 

@@ -66,43 +66,72 @@ def halo_tensors(solver):
 
 
 class HaloExchanger(object):
-    """Posts the two per-iteration exchanges of one block as batched isend/irecv."""
+    """Posts the two per-iteration exchanges of one block as batched isend/irecv.
+
+    With the "nccl" backend (RCCL) the device frames are sent as they are.  A
+    backend without device point-to-point (gloo) gets them staged through pinned
+    host memory; that mode exists for functional tests of the multi-process path
+    on a machine with fewer GPUs than ranks, not for speed.
+    """
 
     def __init__(self, tensors, rank, world, group=None):
+        import torch
         import torch.distributed as dist
+        self.torch = torch
         self.dist = dist
         self.t = tensors
         self.prev = rank - 1 if rank > 0 else None
         self.next = rank + 1 if rank < world - 1 else None
         self.group = group
+        on_device = any(t is not None and t.is_cuda for ts in tensors.values() for t in ts)
+        self.staged = on_device and dist.get_backend(group) != "nccl"
+        self.host = {}
+        if self.staged:
+            for name, ts in tensors.items():
+                self.host[name] = [None if t is None else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                                   for t in ts]
 
-    def _post(self, ops):
-        if not ops:
-            return []
-        return self.dist.batch_isend_irecv(ops)
+    def _start(self, send_name, send_to, recv_name, recv_from):
+        P2POp, d = self.dist.P2POp, self.dist
+        ops, after = [], []
+        if send_to is not None:
+            for k, t in enumerate(self.t[send_name]):
+                if t is None:
+                    continue
+                if self.staged:
+                    self.host[send_name][k].copy_(t, non_blocking=True)
+                    t = self.host[send_name][k]
+                ops.append(P2POp(d.isend, t, send_to, self.group))
+        if recv_from is not None:
+            for k, t in enumerate(self.t[recv_name]):
+                if t is None:
+                    continue
+                if self.staged:
+                    after.append((t, self.host[recv_name][k]))
+                    t = self.host[recv_name][k]
+                ops.append(P2POp(d.irecv, t, recv_from, self.group))
+        if self.staged and ops:
+            self.torch.cuda.current_stream().synchronize()      # host copies of the outgoing frames are complete
+        reqs = self.dist.batch_isend_irecv(ops) if ops else []
+        return (reqs, after)
 
     def start_xbar(self):
-        P2POp, d = self.dist.P2POp, self.dist
-        ops = []
-        if self.prev is not None:
-            ops += [P2POp(d.isend, t, self.prev, self.group) for t in self.t["send_prev"] if t is not None]
-        if self.next is not None:
-            ops += [P2POp(d.irecv, t, self.next, self.group) for t in self.t["recv_next"] if t is not None]
-        return self._post(ops)
+        """xbar of the first local frame -> previous rank; ghost of the next rank's first frame <- next."""
+        return self._start("send_prev", self.prev, "recv_next", self.next)
 
     def start_dual(self):
-        P2POp, d = self.dist.P2POp, self.dist
-        ops = []
-        if self.next is not None:
-            ops += [P2POp(d.isend, t, self.next, self.group) for t in self.t["send_next"] if t is not None]
-        if self.prev is not None:
-            ops += [P2POp(d.irecv, t, self.prev, self.group) for t in self.t["recv_prev"] if t is not None]
-        return self._post(ops)
+        """temporal duals of the last local frame -> next rank; ghost of the previous rank's <- previous."""
+        return self._start("send_next", self.next, "recv_prev", self.prev)
 
     @staticmethod
-    def wait(reqs):
-        for r in reqs or []:
+    def wait(pending):
+        if not pending:
+            return
+        reqs, after = pending
+        for r in reqs:
             r.wait()
+        for dev, host in after:
+            dev.copy_(host, non_blocking=True)
 
 
 def allreduce_sums(values, device=None):
@@ -137,7 +166,7 @@ def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=N
     if check_every <= 0:
         check_every = max(max_iters, 1)
     stats = {"iterations": 0, "converged": False, "res_primal": 0.0, "res_dual": 0.0}
-    reqs_dual = []
+    reqs_dual = None
     for it in range(max_iters):
         check = ((it + 1) % check_every == 0) or it == max_iters - 1
         if check:

@@ -195,6 +195,13 @@ class FrameBlockSolver(object):
         self._check(self._lib.mmc_get_profile(self._h, ms, C.byref(n)))
         return {"primal_ms": ms[0], "dual_reg_ms": ms[1], "dual_data_ms": ms[2], "iterations": n.value}
 
+    def get_sweep_profile(self):
+        """Summed duration (ms) and count of the profiled mmc_sweep_* calls."""
+        ms = (C.c_double * 2)()
+        n = (C.c_int * 2)()
+        self._check(self._lib.mmc_get_sweep_profile(self._h, ms, n))
+        return {"primal_ms": ms[0], "dual_ms": ms[1], "primal_calls": n[0], "dual_calls": n[1]}
+
     def energy(self):
         v = C.c_double()
         self._check(self._lib.mmc_energy(self._h, C.byref(v)))

@@ -1,0 +1,70 @@
+"""Two real processes, one frame block each, sharing the one visible GPU: the
+product's sharded solve (FrameBlockSolver + sharding.solve_sharded) with the
+halo frames exchanged over torch.distributed.  The backend is gloo with
+host-staged frames (RCCL refuses two ranks on one device); everything else --
+block set-up, all-reduced h, stream handling, sweep/exchange order -- is the
+path bench.py runs with --gpus N."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import mmc_oracle as orc
+from helpers import make_case, rel_l2
+
+pytestmark = pytest.mark.gpu
+KBLUR = orc.fspecial_gaussian(7, np.sqrt(0.6))
+
+
+def _worker(rank, world, port, nc, kappa, direction, iters, out_dir):
+    import torch
+    import torch.distributed as dist
+    from superresolution_amd import sharding
+    from superresolution_amd.solver import FrameBlockSolver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        torch.cuda.set_stream(torch.cuda.Stream())
+        f, v, occ = make_case(41, 8, 10, nc, flow="smooth", flow_scale=2.0, with_occ=True)
+        P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
+        a, b = sharding.partition_frames(nc, world)[rank]
+        lo, hi = sharding.pairs_needed(a, b, nc)
+        s0, s1 = sharding.state_frames_needed(a, b, nc)
+        s = FrameBlockSolver(8, 10, 4, nc, a, b, alpha=P.alpha, kappa=kappa, h=0.0, flow_direction=direction,
+                             device=0, stream=torch.cuda.current_stream().cuda_stream)
+        s.set_lowres(f[:, :, a:b]); s.set_blur(KBLUR); s.set_flow(v[:, :, lo:hi, :], occ[:, :, lo:hi])
+        s.set_state(P.u_up[:, :, s0:s1], P.u_up[:, :, s0:s1])
+        s.init()
+        s.h = sharding.sharded_h(s, "cuda:0")
+        ex = sharding.HaloExchanger(sharding.halo_tensors(s), rank, world)
+        assert ex.staged
+        st = sharding.solve_sharded(s, ex, iters, 0.0, 10, "cuda:0")
+        u, w = s.get_state()
+        np.savez(os.path.join(out_dir, "r%d.npz" % rank), a=a, b=b, u=u, h=s.h,
+                 res=np.array([st["res_primal"], st["res_dual"]]), **({} if w is None else {"w": w}))
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nc,kappa,direction", [(2, 5, 0.25, "backward"), (3, 6, float("nan"), "forward-backward")])
+def test_two_processes_one_gpu(tmp_path, world, nc, kappa, direction):
+    import torch.multiprocessing as mp
+    iters = 30
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    mp.spawn(_worker, args=(world, port, nc, kappa, direction, iters, str(tmp_path)), nprocs=world, join=True)
+    f, v, occ = make_case(41, 8, 10, nc, flow="smooth", flow_scale=2.0, with_occ=True)
+    P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
+    x, _, chg = orc.pdhg(P, iters)
+    u_ref, w_ref = orc.split_primal(P, x)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        a, b = int(d["a"]), int(d["b"])
+        assert abs(float(d["h"]) - P.h) < 1e-5 * P.h
+        assert rel_l2(d["u"], u_ref[:, :, a:b]) < 1e-4
+        if w_ref is not None:
+            assert np.abs(d["w"] - w_ref[:, :, a:b]).max() < 1e-4
+        assert abs(d["res"][0] - chg[0] / chg[1]) < 2e-2 * chg[0] / chg[1] + 1e-7
