@@ -49,8 +49,9 @@ def parse():
 
 
 def cpu_baseline(args, budget_s):
-    """The oracle's PDHG iteration timed on the host: a bounded sample of the
-    same workload (a 64x96-LR crop of its first 3 frames)."""
+    """The oracle's PDHG iteration timed on the host cores: a bounded sample of the same
+    workload (first 6 frames, 544x960 HR) with the C/OpenMP restatement, or, if that cannot
+    be built, a smaller crop with the scipy.sparse restatement on one core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from superresolution_amd import synthetic
     try:

@@ -1,0 +1,393 @@
+/*
+ * mmc_oracle_c.c -- C/OpenMP restatement of the Multiframe Motion Coupling PDHG
+ * solve.  TEST INFRASTRUCTURE ONLY: it is the second checker next to
+ * oracle/mmc_oracle.py and the CPU baseline timed by bench.py; nothing in the
+ * product package links or loads it.  PARITY UNPINNED against real
+ * prost/flexBox output (the reference cannot run here and ships no vectors); it
+ * is validated against oracle/mmc_oracle.py in tests/test_oracle_c.py.
+ *
+ * It follows what the reference hands to flexBox_CPP (explicit sparse operators,
+ * MultiframeMotionCoupling.m:724-745): W and W' (helpers/constructWarpFF.m,
+ * constructWarpFB.m) and A = D*B and A' (helpers/samplingOperator.m,
+ * helpers/RepConvMtx.m) are stored as sparse rows, the gradient
+ * (spmat_gradient2d) is applied matrix-free, the problem is the one of
+ * init_u_prost (MultiframeMotionCoupling.m:480-533), the iteration and the step
+ * sizes are those fixed in oracle/mmc_oracle.py (DECISION comments there).
+ * float32 arithmetic throughout, double only for the reported sums.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -fopenmp -shared).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct mmco_params {
+    int ny, nx, factor, nc;
+    float alpha, kappa, h;      /* kappa NaN: additive model; 1: single-dual model; h <= 0: compute */
+    int flow_direction;         /* 0 forward 'F-I', 1 backward 'I-F', 2 forward-backward */
+    int sampling;               /* 0 'average' (factor 4), 1 'stride' */
+    int kh, kw;                 /* blur kernel size, 0 = no blur */
+} mmco_params;
+
+typedef struct { int *ptr, *idx; float *val; int rows; } csr;
+
+static void csr_free(csr *m) { free(m->ptr); free(m->idx); free(m->val); memset(m, 0, sizeof(*m)); }
+
+/* transpose of a rows x cols CSR by counting sort */
+static csr csr_transpose(const csr *a, int cols) {
+    csr t;
+    int nnz = a->ptr[a->rows], i, k;
+    t.rows = cols;
+    t.ptr = (int *)calloc((size_t)cols + 1, sizeof(int));
+    t.idx = (int *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(int));
+    t.val = (float *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(float));
+    for (k = 0; k < nnz; ++k) t.ptr[a->idx[k] + 1]++;
+    for (i = 0; i < cols; ++i) t.ptr[i + 1] += t.ptr[i];
+    {
+        int *fill = (int *)malloc((size_t)cols * sizeof(int));
+        memcpy(fill, t.ptr, (size_t)cols * sizeof(int));
+        for (i = 0; i < a->rows; ++i)
+            for (k = a->ptr[i]; k < a->ptr[i + 1]; ++k) {
+                int c = a->idx[k], pos = fill[c]++;
+                t.idx[pos] = i;
+                t.val[pos] = a->val[k];
+            }
+        free(fill);
+    }
+    return t;
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* A = D*B for one frame: row (R,C) of samplingOperator * RepConvMtx with the replicate border of
+ * RepConvMtx.m:23-32; taps that clamp onto the same pixel are merged (sparse() sums duplicates, :38). */
+static csr build_A(const mmco_params *P, const float *k) {
+    const int f = P->factor, Ny = P->ny * f, Nx = P->nx * f;
+    const int td = P->sampling == 0 ? f : 1;
+    const int kh = P->kh > 0 ? P->kh : 1, kw = P->kw > 0 ? P->kw : 1;
+    const int ker = kh / 2, kec = kw / 2;
+    const int maxrow = td * td * kh * kw;
+    const float wd = 1.0f / (float)(td * td);
+    csr A;
+    int R, C, n = P->ny * P->nx, nnz = 0;
+    A.rows = n;
+    A.ptr = (int *)calloc((size_t)n + 1, sizeof(int));
+    A.idx = (int *)malloc((size_t)n * maxrow * sizeof(int));
+    A.val = (float *)malloc((size_t)n * maxrow * sizeof(float));
+    for (C = 0; C < P->nx; ++C)
+        for (R = 0; R < P->ny; ++R) {
+            const int row = R + P->ny * C, start = nnz;
+            int a, b, i, j, e;
+            for (b = 0; b < td; ++b)
+                for (a = 0; a < td; ++a)
+                    for (j = -kec; j <= kec; ++j)
+                        for (i = -ker; i <= ker; ++i) {
+                            /* (B u)(r,c) = sum k(kc-i, kc-j) u(clamp(r+i), clamp(c+j)), RepConvMtx.m:33 */
+                            const float kv = P->kh > 0 ? k[(ker - i) + kh * (kec - j)] : 1.0f;
+                            const int rr = clampi(f * R + a + i, 0, Ny - 1), cc = clampi(f * C + b + j, 0, Nx - 1);
+                            const int col = rr + Ny * cc;
+                            for (e = start; e < nnz; ++e)
+                                if (A.idx[e] == col) break;
+                            if (e == nnz) { A.idx[nnz] = col; A.val[nnz] = 0.0f; nnz++; }
+                            A.val[e] += wd * kv;
+                        }
+            A.ptr[row + 1] = nnz;
+            (void)row;
+        }
+    return A;
+}
+
+typedef struct { int idx[4]; float w[4]; int valid; } taps;
+
+/* bilinear taps of warpingOperator as fixed in oracle/mmc_oracle.py: float32 position arithmetic,
+ * row masked when the sample leaves the closed pixel domain or is NaN, +1 tap index clamped */
+static taps make_taps(int Ny, int Nx, int r, int c, float vx, float vy) {
+    taps t;
+    float y = (float)r + vy, x = (float)c + vx, y0, x0, a, b, na, nb;
+    int r0, c0, r1, c1;
+    t.valid = (y >= 0.0f) && (y <= (float)(Ny - 1)) && (x >= 0.0f) && (x <= (float)(Nx - 1));
+    if (!t.valid) { y = 0.0f; x = 0.0f; }
+    y0 = floorf(y); x0 = floorf(x);
+    a = y - y0; b = x - x0; na = 1.0f - a; nb = 1.0f - b;
+    r0 = (int)y0; c0 = (int)x0;
+    r1 = r0 + 1 < Ny ? r0 + 1 : Ny - 1;
+    c1 = c0 + 1 < Nx ? c0 + 1 : Nx - 1;
+    t.idx[0] = r0 + Ny * c0; t.idx[1] = r1 + Ny * c0; t.idx[2] = r0 + Ny * c1; t.idx[3] = r1 + Ny * c1;
+    t.w[0] = na * nb; t.w[1] = a * nb; t.w[2] = na * b; t.w[3] = a * b;
+    return t;
+}
+
+static int pair_is_IF(int dir, int q) { return dir == 1 ? 1 : (dir == 0 ? 0 : ((q & 1) == 0)); }
+
+/* Returns 0 on success.  u, w: start point in, result out (w may be NULL for the models without w).
+ * out[0..3] = sum(x+-x)^2, sum(x+)^2, sum(y+-y)^2, sum(y+)^2 of the last iteration, out[4] = h,
+ * out[5] = seconds spent in the iteration loop, out[6] = threads used. */
+int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const unsigned char *occ,
+               const float *k, float *u, float *w, int iters, int nthreads, double *out) {
+    const int f = P->factor, ny = P->ny, nx = P->nx, nc = P->nc, Ny = ny * f, Nx = nx * f;
+    const int N = Ny * Nx, n = ny * nx, npairs = nc > 1 ? nc - 1 : 0;
+    const size_t M = (size_t)N * nc;
+    const int model = isnan(P->kappa) ? 2 : (P->kappa == 1.0f ? 1 : 0);
+    const float kap = model == 0 ? P->kappa : 1.0f;
+    const float rad1 = model == 1 ? 2.0f * P->alpha : P->alpha, rad2 = P->alpha;
+    csr A, AT, *WT;
+    taps *tp;
+    float *cW, *cA, *sigp, *ub, *wb, *p, *g1, *g2, h, inv_h;
+    double s_dx = 0, s_x = 0, s_dy = 0, s_y = 0, t_loop = 0;
+    int q, it;
+    long long jj;
+    if ((P->sampling == 0 && f != 4) || (P->kh > 0 && ((P->kh & 1) == 0 || (P->kw & 1) == 0))) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    A = build_A(P, k);
+    AT = csr_transpose(&A, N);
+    tp = (taps *)malloc((size_t)(npairs > 0 ? npairs : 1) * N * sizeof(taps));
+    WT = (csr *)calloc((size_t)(npairs > 0 ? npairs : 1), sizeof(csr));
+    cW = (float *)calloc(M, sizeof(float));
+    /* constructWarpFF.m:22-38: taps, out-of-range / occlusion marker; W' as sparse rows per pair */
+    for (q = 0; q < npairs; ++q) {
+        csr Wq;
+        int j, e, nnz = 0;
+        Wq.rows = N;
+        Wq.ptr = (int *)calloc((size_t)N + 1, sizeof(int));
+        Wq.idx = (int *)malloc((size_t)4 * N * sizeof(int));
+        Wq.val = (float *)malloc((size_t)4 * N * sizeof(float));
+        for (j = 0; j < N; ++j) {
+            taps t = make_taps(Ny, Nx, j % Ny, j / Ny, v[(size_t)q * N + j], v[(size_t)(npairs + q) * N + j]);
+            if (occ && occ[(size_t)q * N + j]) t.valid = 0;
+            tp[(size_t)q * N + j] = t;
+            if (t.valid)
+                for (e = 0; e < 4; ++e) { Wq.idx[nnz] = t.idx[e]; Wq.val[nnz] = t.w[e]; nnz++; }
+            Wq.ptr[j + 1] = nnz;
+        }
+        WT[q] = csr_transpose(&Wq, N);
+        {   /* column abs-sums of the coupling operator: warp part on the warped frame, -Id on the other */
+            const int isIF = pair_is_IF(P->flow_direction, q);
+            float *cw_w = cW + (size_t)(isIF ? q + 1 : q) * N, *cw_i = cW + (size_t)(isIF ? q : q + 1) * N;
+            for (j = 0; j < N; ++j) {
+                for (e = WT[q].ptr[j]; e < WT[q].ptr[j + 1]; ++e) cw_w[j] += WT[q].val[e];
+                if (tp[(size_t)q * N + j].valid) cw_i[j] += 1.0f;
+            }
+        }
+        csr_free(&Wq);
+    }
+    /* abs row / column sums of A */
+    cA = (float *)calloc((size_t)N, sizeof(float));
+    sigp = (float *)malloc((size_t)n * sizeof(float));
+    {
+        int i, e;
+        for (i = 0; i < n; ++i) {
+            float s = 0.0f;
+            for (e = A.ptr[i]; e < A.ptr[i + 1]; ++e) { s += fabsf(A.val[e]); cA[A.idx[e]] += fabsf(A.val[e]); }
+            sigp[i] = s > 0.0f ? 1.0f / s : 1.0f;
+        }
+    }
+    ub = (float *)malloc(M * sizeof(float));
+    wb = (float *)calloc(M, sizeof(float));
+    memcpy(ub, u, M * sizeof(float));
+    if (model == 0) memcpy(wb, w, M * sizeof(float));
+    p = (float *)calloc((size_t)n * nc, sizeof(float));
+    g1 = (float *)calloc(3 * M, sizeof(float));
+    g2 = (float *)calloc(3 * M, sizeof(float));
+
+    /* h = (sum|W u|/M) / (sum|G u|/M) on the start point, MultiframeMotionCoupling.m:431-437 */
+    h = P->h;
+    if (!(h > 0.0f)) {
+        double sw = 0.0, sg = 0.0;
+#pragma omp parallel for reduction(+ : sw, sg) schedule(static)
+        for (jj = 0; jj < (long long)M; ++jj) {
+            const int t = (int)(jj / N), j = (int)(jj % N), r = j % Ny, c = j / Ny;
+            const float *ut = u + (size_t)t * N;
+            if (c < Nx - 1) sg += fabs((double)(ut[j + Ny] - ut[j]));
+            if (r < Ny - 1) sg += fabs((double)(ut[j + 1] - ut[j]));
+            if (t < npairs && tp[(size_t)t * N + j].valid) {
+                const taps *tt = &tp[(size_t)t * N + j];
+                const int isIF = pair_is_IF(P->flow_direction, t);
+                const float *uw = u + (size_t)(isIF ? t + 1 : t) * N, *ui = u + (size_t)(isIF ? t : t + 1) * N;
+                sw += fabs((double)(tt->w[0] * uw[tt->idx[0]] + tt->w[1] * uw[tt->idx[1]] + tt->w[2] * uw[tt->idx[2]] +
+                                    tt->w[3] * uw[tt->idx[3]] - ui[j]));
+            }
+        }
+        h = nc == 1 ? 1.0f : (float)(sw / sg);
+    }
+    inv_h = 1.0f / h;
+
+    {
+#ifdef _OPENMP
+        double t0 = omp_get_wtime();
+#endif
+        for (it = 0; it < iters; ++it) {
+            const int last = it == iters - 1;
+            double a_dx = 0, a_x = 0, a_dy = 0, a_y = 0;
+            /* primal: x+ = prox_G(x - T K'y), xbar = 2x+ - x */
+#pragma omp parallel for reduction(+ : a_dx, a_x) schedule(static)
+            for (jj = 0; jj < (long long)M; ++jj) {
+                const int t = (int)(jj / N), j = (int)(jj % N), r = j % Ny, c = j / Ny;
+                const size_t o = (size_t)t * N;
+                float Wt1 = 0.0f, Wt2 = 0.0f, ATp = 0.0f, div1 = 0.0f, div2 = 0.0f, cgrad, cw, tau_u, KTu, un, uo;
+                int e, qq;
+                for (qq = t - 1; qq <= t; ++qq) {
+                    int isIF;
+                    if (qq < 0 || qq >= npairs) continue;
+                    isIF = pair_is_IF(P->flow_direction, qq);
+                    if ((qq == t - 1) == isIF) {            /* warp of pair qq samples frame t */
+                        const csr *m = &WT[qq];
+                        const float *a1 = g1 + (size_t)qq * N, *a2 = g2 + (size_t)qq * N;
+                        for (e = m->ptr[j]; e < m->ptr[j + 1]; ++e) {
+                            Wt1 += m->val[e] * a1[m->idx[e]];
+                            if (model == 0) Wt2 += m->val[e] * (kap * a2[m->idx[e]] - a1[m->idx[e]]);
+                        }
+                    } else if (tp[(size_t)qq * N + j].valid) { /* -Id block of pair qq sits on frame t */
+                        Wt1 -= g1[(size_t)qq * N + j];
+                        if (model == 0) Wt2 -= kap * g2[(size_t)qq * N + j] - g1[(size_t)qq * N + j];
+                    }
+                }
+                for (e = AT.ptr[j]; e < AT.ptr[j + 1]; ++e) ATp += AT.val[e] * p[(size_t)t * n + AT.idx[e]];
+                {
+                    const float *gx = g1 + M + o, *gy = g1 + 2 * M + o;
+                    if (c > 0) div1 += gx[j - Ny];
+                    if (c < Nx - 1) div1 -= gx[j];
+                    if (r > 0) div1 += gy[j - 1];
+                    if (r < Ny - 1) div1 -= gy[j];
+                }
+                cgrad = (float)((c < Nx - 1) + (c > 0) + (r < Ny - 1) + (r > 0));
+                cw = cW[o + j] * inv_h;
+                KTu = ATp + inv_h * Wt1 + kap * div1;
+                tau_u = 1.0f / (cA[j] + cw + kap * cgrad);
+                uo = u[o + j];
+                un = uo - tau_u * KTu;
+                un = un < 0.0f ? 0.0f : (un > 1.0f ? 1.0f : un);          /* G = ind[0,1], :495 */
+                u[o + j] = un;
+                ub[o + j] = 2.0f * un - uo;
+                if (last) { a_dx += (double)(un - uo) * (un - uo); a_x += (double)un * un; }
+                if (model == 0) {
+                    const float *gx = g2 + M + o, *gy = g2 + 2 * M + o;
+                    float KTw, tau_w, wo, wn;
+                    if (c > 0) div2 += gx[j - Ny];
+                    if (c < Nx - 1) div2 -= gx[j];
+                    if (r > 0) div2 += gy[j - 1];
+                    if (r < Ny - 1) div2 -= gy[j];
+                    KTw = inv_h * Wt2 - kap * div1 + div2;
+                    tau_w = 1.0f / ((1.0f + kap) * (cw + cgrad));
+                    wo = w[o + j];
+                    wn = wo - tau_w * KTw;
+                    w[o + j] = wn;
+                    wb[o + j] = 2.0f * wn - wo;
+                    if (last) { a_dx += (double)(wn - wo) * (wn - wo); a_x += (double)wn * wn; }
+                }
+            }
+            /* dual, data term: p <- clamp(p + s (A xbar - f), -1, 1), :496 */
+#pragma omp parallel for reduction(+ : a_dy, a_y) schedule(static)
+            for (jj = 0; jj < (long long)n * nc; ++jj) {
+                const int t = (int)(jj / n), i = (int)(jj % n);
+                const float *x = ub + (size_t)t * N;
+                float acc = 0.0f, po = p[jj], pn;
+                int e;
+                for (e = A.ptr[i]; e < A.ptr[i + 1]; ++e) acc += A.val[e] * x[A.idx[e]];
+                pn = po + sigp[i] * (acc - f_lr[jj]);
+                pn = pn < -1.0f ? -1.0f : (pn > 1.0f ? 1.0f : pn);
+                p[jj] = pn;
+                if (last) { a_dy += (double)(pn - po) * (pn - po); a_y += (double)pn * pn; }
+            }
+            /* dual, regulariser: g <- proj(g + S K xbar), :497-498, :513, :532-533 */
+#pragma omp parallel for reduction(+ : a_dy, a_y) schedule(static)
+            for (jj = 0; jj < (long long)M; ++jj) {
+                const int t = (int)(jj / N), j = (int)(jj % N), r = j % Ny, c = j / Ny;
+                const size_t o = (size_t)t * N;
+                const int hasx = c < Nx - 1, hasy = r < Ny - 1;
+                const float *x = ub + o, *z = wb + o;
+                const float uc = x[j], ux = hasx ? x[j + Ny] : uc, uy = hasy ? x[j + 1] : uc;
+                const float wc = z[j], wx = hasx ? z[j + Ny] : wc, wy = hasy ? z[j + 1] : wc;
+                float tu = 0.0f, tw = 0.0f, k1t, k1x, k1y, k2t = 0, k2x = 0, k2y = 0, rs1, rs2 = 0.0f, sg1, sg2;
+                float n1t, n1x, n1y, o1t = g1[o + j], o1x = g1[M + o + j], o1y = g1[2 * M + o + j], nrm;
+                int valid = 0;
+                if (t < npairs) {
+                    const taps *tt = &tp[o + j];
+                    valid = tt->valid;
+                    if (valid) {
+                        const int isIF = pair_is_IF(P->flow_direction, t);
+                        const size_t ow = (size_t)(isIF ? t + 1 : t) * N, oi = (size_t)(isIF ? t : t + 1) * N;
+                        tu = tt->w[0] * ub[ow + tt->idx[0]] + tt->w[1] * ub[ow + tt->idx[1]] + tt->w[2] * ub[ow + tt->idx[2]] +
+                             tt->w[3] * ub[ow + tt->idx[3]] - ub[oi + j];
+                        if (model == 0)
+                            tw = tt->w[0] * wb[ow + tt->idx[0]] + tt->w[1] * wb[ow + tt->idx[1]] +
+                                 tt->w[2] * wb[ow + tt->idx[2]] + tt->w[3] * wb[ow + tt->idx[3]] - wb[oi + j];
+                    }
+                }
+                if (model == 0) {
+                    const float dc = uc - wc;
+                    k1t = (tu - tw) * inv_h;
+                    k1x = hasx ? kap * ((ux - wx) - dc) : 0.0f;
+                    k1y = hasy ? kap * ((uy - wy) - dc) : 0.0f;
+                    k2t = kap * tw * inv_h;
+                    k2x = hasx ? wx - wc : 0.0f;
+                    k2y = hasy ? wy - wc : 0.0f;
+                    rs1 = fmaxf(valid ? 4.0f * inv_h : 0.0f, fmaxf(hasx ? 4.0f * kap : 0.0f, hasy ? 4.0f * kap : 0.0f));
+                    rs2 = fmaxf(valid ? 2.0f * kap * inv_h : 0.0f, fmaxf(hasx ? 2.0f : 0.0f, hasy ? 2.0f : 0.0f));
+                } else {
+                    k1t = tu * inv_h;
+                    k1x = hasx ? ux - uc : 0.0f;
+                    k1y = hasy ? uy - uc : 0.0f;
+                    if (model == 1) {
+                        rs1 = fmaxf(valid ? 2.0f * inv_h : 0.0f, fmaxf(hasx ? 2.0f : 0.0f, hasy ? 2.0f : 0.0f));
+                    } else {
+                        rs1 = valid ? 2.0f * inv_h : 0.0f;
+                        rs2 = fmaxf(hasx ? 2.0f : 0.0f, hasy ? 2.0f : 0.0f);
+                    }
+                }
+                sg1 = rs1 > 0.0f ? 1.0f / rs1 : 1.0f;
+                sg2 = rs2 > 0.0f ? 1.0f / rs2 : 1.0f;
+                if (model == 2) {
+                    n1t = valid ? o1t + sg1 * k1t : 0.0f;
+                    n1t = n1t < -rad1 ? -rad1 : (n1t > rad1 ? rad1 : n1t);
+                    n1x = o1x + sg2 * k1x;
+                    n1y = o1y + sg2 * k1y;
+                    nrm = sqrtf(n1x * n1x + n1y * n1y);
+                    if (nrm > rad2) { n1x *= rad2 / nrm; n1y *= rad2 / nrm; }
+                } else {
+                    n1t = valid ? o1t + sg1 * k1t : 0.0f;
+                    n1x = o1x + sg1 * k1x;
+                    n1y = o1y + sg1 * k1y;
+                    nrm = sqrtf(n1t * n1t + n1x * n1x + n1y * n1y);
+                    if (nrm > rad1) { const float sc = rad1 / nrm; n1t *= sc; n1x *= sc; n1y *= sc; }
+                }
+                g1[o + j] = n1t; g1[M + o + j] = n1x; g1[2 * M + o + j] = n1y;
+                if (last) {
+                    a_dy += (double)(n1t - o1t) * (n1t - o1t) + (double)(n1x - o1x) * (n1x - o1x) + (double)(n1y - o1y) * (n1y - o1y);
+                    a_y += (double)n1t * n1t + (double)n1x * n1x + (double)n1y * n1y;
+                }
+                if (model == 0) {
+                    const float o2t = g2[o + j], o2x = g2[M + o + j], o2y = g2[2 * M + o + j];
+                    float n2t = valid ? o2t + sg2 * k2t : 0.0f, n2x = o2x + sg2 * k2x, n2y = o2y + sg2 * k2y;
+                    nrm = sqrtf(n2t * n2t + n2x * n2x + n2y * n2y);
+                    if (nrm > rad2) { const float sc = rad2 / nrm; n2t *= sc; n2x *= sc; n2y *= sc; }
+                    g2[o + j] = n2t; g2[M + o + j] = n2x; g2[2 * M + o + j] = n2y;
+                    if (last) {
+                        a_dy += (double)(n2t - o2t) * (n2t - o2t) + (double)(n2x - o2x) * (n2x - o2x) + (double)(n2y - o2y) * (n2y - o2y);
+                        a_y += (double)n2t * n2t + (double)n2x * n2x + (double)n2y * n2y;
+                    }
+                }
+            }
+            if (last) { s_dx = a_dx; s_x = a_x; s_dy = a_dy; s_y = a_y; }
+        }
+#ifdef _OPENMP
+        t_loop = omp_get_wtime() - t0;
+#endif
+    }
+    if (out) {
+        out[0] = s_dx; out[1] = s_x; out[2] = s_dy; out[3] = s_y; out[4] = h; out[5] = t_loop;
+#ifdef _OPENMP
+        out[6] = omp_get_max_threads();
+#else
+        out[6] = 1;
+#endif
+    }
+    for (q = 0; q < npairs; ++q) csr_free(&WT[q]);
+    free(WT); free(tp); free(cW); free(cA); free(sigp); free(ub); free(wb); free(p); free(g1); free(g2);
+    csr_free(&A); csr_free(&AT);
+    return 0;
+}
