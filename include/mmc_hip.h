@@ -150,6 +150,14 @@ int mmc_num_flow_pairs(const mmc_handle *h);
 int mmc_set_state(mmc_handle *h, const float *u, const float *w);
 int mmc_num_state_frames(const mmc_handle *h);
 
+/* Pins the first frame of the SEQUENCE to (u0, w0), each Ny x Nx: the two extra
+ * duals q1, q2 with identity blocks and F*(q) = <x0, q> of
+ * MultiframeMotionCoupling.m:535-572, used to chain batches of a long video
+ * (variants/VideoProcessor_supplementary_MMC.m:119-176).  Infimal-convolution
+ * model only.  Blocks that do not hold frame 0 accept and ignore it; NULL, NULL
+ * removes the constraint; one NULL is the reference's error (:190-192). */
+int mmc_set_fixed_frame(mmc_handle *h, const float *u0, const float *w0);
+
 /* Out-of-range / occlusion masks, column sums of the warp, tile source boxes,
  * step sizes and (when params.h <= 0) h from this block's own sums.
  * Replaces the one-off part of init_u_prost, MultiframeMotionCoupling.m:389-437. */

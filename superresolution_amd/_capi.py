@@ -68,6 +68,7 @@ SIGNATURES = {
     "mmc_num_flow_pairs": (C.c_int, [_H]),
     "mmc_set_state": (C.c_int, [_H, _fp, _fp]),
     "mmc_num_state_frames": (C.c_int, [_H]),
+    "mmc_set_fixed_frame": (C.c_int, [_H, _fp, _fp]),
     "mmc_init": (C.c_int, [_H]),
     "mmc_h_partials": (C.c_int, [_H, _dp]),
     "mmc_set_h": (C.c_int, [_H, C.c_float]),

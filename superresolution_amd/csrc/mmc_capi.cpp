@@ -166,6 +166,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.ckp, (size_t)(MMC_MAX_CK + p->factor) * (MMC_MAX_CK + p->factor))) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.bbox, (size_t)(h->L + 1) * g.ntiles * 4)) != MMC_OK) return bail(rc);
+    { float **fx[] = {&a.q1, &a.q2, &a.u0, &a.w0}; for (float **pp : fx) if ((rc = dev_alloc(h, pp, (size_t)g.N)) != MMC_OK) return bail(rc); }
     if ((rc = dev_alloc(h, &a.tbox, (size_t)h->L * g.ntiles * 4)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &h->scratch, (size_t)g.N)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)) != MMC_OK) return bail(rc);
@@ -267,8 +268,28 @@ extern "C" int mmc_set_state(mmc_handle *h, const float *u, const float *w) {
     float *duals[] = {a.g1t, a.g1x, a.g1y, a.g2t, a.g2x, a.g2y};
     for (float *d : duals) HIPCHK(h, hipMemsetAsync(d, 0, fs, h->stream));
     HIPCHK(h, hipMemsetAsync(a.p, 0, (size_t)h->L * g.n * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(a.q1, 0, (size_t)g.N * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(a.q2, 0, (size_t)g.N * sizeof(float), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_state = true;
+    return MMC_OK;
+}
+
+extern "C" int mmc_set_fixed_frame(mmc_handle *h, const float *u0, const float *w0) {
+    REQUIRE_HANDLE(h);
+    if ((u0 == nullptr) != (w0 == nullptr))
+        return fail(h, MMC_ERR_INVALID_ARG, "Give both fix frames u0 and w0.");      // MultiframeMotionCoupling.m:190-192
+    if (!u0) { h->g.fixed = 0; return MMC_OK; }
+    if (h->g.model != MODEL_IC)
+        return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_fixed_frame: the fixed first frame exists only for the infimal-convolution model (kappa not 1, not NaN)");
+    int rc = use_device(h); if (rc) return rc;
+    const size_t B = (size_t)h->g.N * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(h->a.u0, u0, B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->a.w0, w0, B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->a.q1, 0, B, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->a.q2, 0, B, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->g.fixed = 1;      // only the block that holds frame 0 of the sequence acts on it
     return MMC_OK;
 }
 
@@ -662,6 +683,8 @@ static int zero_duals(mmc_handle *h) {
     float *duals[] = {a.g1t, a.g1x, a.g1y, a.g2t, a.g2x, a.g2y};
     for (float *d : duals) HIPCHK(h, hipMemsetAsync(d, 0, fs, h->stream));
     HIPCHK(h, hipMemsetAsync(a.p, 0, (size_t)h->L * g.n * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(a.q1, 0, (size_t)g.N * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(a.q2, 0, (size_t)g.N * sizeof(float), h->stream));
     return MMC_OK;
 }
 

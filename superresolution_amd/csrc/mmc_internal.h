@@ -39,6 +39,7 @@ struct Geom {
     int tiles_r, tiles_c, ntiles;
     float alpha, kappa, inv_h;
     float radius1, radius2;    // projection radii of the g1 / g2 groups
+    int fixed;                 // 1: first frame of the sequence is pinned to (u0, w0), MultiframeMotionCoupling.m:535-572
     int dbg;                   // ablation switches for kernel tuning (env MMC_DEBUG), 0 in production
 };
 
@@ -52,6 +53,8 @@ struct Arrays {
     float *g2t, *g2x, *g2y;    // dual of K2
     float *vx, *vy;            // flow of pair t (frame t <-> t+1); NaN = masked
     float *cW;                 // column abs-sum of the motion-coupling operator
+    float *q1, *q2;            // duals of the first-frame constraint u_1 = u0, w_1 = w0 (one frame each)
+    float *u0, *w0;            // the pinned first frame
     float *p, *f;              // data-term dual and low-res data, L*n
     float *cA;                 // column abs-sum of D*B, N
     float *sigp;               // 1 / row abs-sum of D*B, n

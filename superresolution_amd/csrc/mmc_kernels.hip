@@ -267,9 +267,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
         const float cgrad = (float)((c < g.Nx - 1) + (c > 0) + (r < g.Ny - 1) + (r > 0));
         const float cw = cW[j] * g.inv_h;
         float tau_u, tau_w = 0.f;
+        const bool isfix = MODEL == MODEL_IC && g.fixed && g.frame_begin + t == 0;   // identity rows of q1, q2 (:560-561)
         if (MODEL == MODEL_IC) {
-            tau_u = 1.f / (a.cA[j] + cw + kap * cgrad);
-            tau_w = 1.f / ((1.f + kap) * (cw + cgrad));
+            tau_u = 1.f / (a.cA[j] + cw + kap * cgrad + (isfix ? 1.f : 0.f));
+            tau_w = 1.f / ((1.f + kap) * (cw + cgrad) + (isfix ? 1.f : 0.f));
         } else {
             tau_u = 1.f / (a.cA[j] + cw + cgrad);
         }
@@ -291,11 +292,12 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
         }
         const float div1 = grad_adj(g, g1x, g1y, r, c, j);
         const float ATp = gather_ATp(g, a.cker, p, r, c);
-        const float KTu = ATp + g.inv_h * Wt1 + kap * div1;
+        float KTu = ATp + g.inv_h * Wt1 + kap * div1;
         float KTw = 0.f;
         if (MODEL == MODEL_IC) {
             const float div2 = grad_adj(g, g2x, g2y, r, c, j);
             KTw = g.inv_h * Wt2 - kap * div1 + div2;
+            if (isfix) { KTu += a.q1[j]; KTw += a.q2[j]; }
         }
         if (MODE == MODE_RAW) {
             ub[j] = KTu;
@@ -470,13 +472,15 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     if (active) {
         float *u = FR(a.u, t) + j, *w = FR(a.w, t) + j, *ub = FR(a.ub, t) + j, *wb = FR(a.wb, t) + j;
         float tau_u[4], tau_w[4];
+        const bool isfix = MODEL == MODEL_IC && g.fixed && g.frame_begin + t == 0;   // identity rows of q1, q2 (:560-561)
+        const float fixc = isfix ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float cgrad = (float)((int)cl + (int)cr + (int)(r + i > 0) + (int)(r + i < g.Ny - 1));
             const float cw = cWv[i] * g.inv_h;
             if (MODEL == MODEL_IC) {
-                tau_u[i] = 1.f / (cAv[i] + cw + kap * cgrad);
-                tau_w[i] = 1.f / ((1.f + kap) * (cw + cgrad));
+                tau_u[i] = 1.f / (cAv[i] + cw + kap * cgrad + fixc);
+                tau_w[i] = 1.f / ((1.f + kap) * (cw + cgrad) + fixc);
             } else {
                 tau_u[i] = 1.f / (cAv[i] + cw + cgrad);
                 tau_w[i] = 0.f;
@@ -542,6 +546,13 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             for (int i = 0; i < 4; ++i) {
                 KTu[i] = ATp[i] + g.inv_h * Wt1[i] + kap * div1[i];
                 KTw[i] = (MODEL == MODEL_IC) ? g.inv_h * Wt2[i] - kap * div1[i] + div2[i] : 0.f;
+            }
+            if (isfix) {
+                float q1v[4], q2v[4];
+                ld4(q1v, a.q1 + j);
+                ld4(q2v, a.q2 + j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { KTu[i] += q1v[i]; KTw[i] += q2v[i]; }
             }
             if (MODE == MODE_RAW) {
                 st4(ub, KTu);
@@ -706,6 +717,16 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) 
             if (REDUCE) {
                 part[0] += (n2t - o2t) * (n2t - o2t) + (n2x - o2x) * (n2x - o2x) + (n2y - o2y) * (n2y - o2y);
                 part[1] += n2t * n2t + n2x * n2x + n2y * n2y;
+            }
+            if (g.fixed && g.frame_begin + t == 0) {
+                // q <- q + (xbar - x0): F*(q) = <x0, q>, identity rows, step 1 (:560-564)
+                const float q1o = a.q1[j], q2o = a.q2[j];
+                const float q1n = q1o + (uc - a.u0[j]), q2n = q2o + (wc - a.w0[j]);
+                a.q1[j] = q1n; a.q2[j] = q2n;
+                if (REDUCE) {
+                    part[0] += (q1n - q1o) * (q1n - q1o) + (q2n - q2o) * (q2n - q2o);
+                    part[1] += q1n * q1n + q2n * q2n;
+                }
             }
         }
     }
@@ -971,6 +992,21 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                     }
                 }
                 st4(g2t, n2t); st4(g2x, n2x); st4(g2y, n2y);
+                if (g.fixed && g.frame_begin + t == 0) {
+                    // q <- q + (xbar - x0): F*(q) = <x0, q>, identity rows, step 1 (:560-564)
+                    float q1o[4], q2o[4], x0u[4], x0w[4], q1n[4], q2n[4];
+                    ld4(q1o, a.q1 + j); ld4(q2o, a.q2 + j); ld4(x0u, a.u0 + j); ld4(x0w, a.w0 + j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        q1n[i] = q1o[i] + (uc[i] - x0u[i]);
+                        q2n[i] = q2o[i] + (wc[i] - x0w[i]);
+                        if (REDUCE) {
+                            part[0] += (q1n[i] - q1o[i]) * (q1n[i] - q1o[i]) + (q2n[i] - q2o[i]) * (q2n[i] - q2o[i]);
+                            part[1] += q1n[i] * q1n[i] + q2n[i] * q2n[i];
+                        }
+                    }
+                    st4(a.q1 + j, q1n); st4(a.q2 + j, q2n);
+                }
             }
         }
     }

@@ -166,8 +166,6 @@ class MultiframeMotionCoupling(object):
         nc = self._numFrames
         iters = 7500 if self.comp_mode == "accurate" else 2500      # :352-356
         self._opts = {"max_iters": iters, "tol": self._tol_pd}
-        if self._u0_frame is not None:
-            raise MMCError(-4, "fixed first frame (u0_frame/w0_frame, :535-572) is not implemented yet")
         v = np.asarray(self._v, dtype=np.float64)
         if v.shape != (Ny, Nx, max(nc - 1, 0), 2) and not (nc == 2 and v.shape == (Ny, Nx, 2)):
             raise ValueError("flowField must be %s, got %s" % ((Ny, Nx, nc - 1, 2), v.shape))
@@ -182,6 +180,10 @@ class MultiframeMotionCoupling(object):
         u0 = u_up if self._u is None else self._u
         w0 = u_up if self._w is None else self._w
         s.set_state(u0, w0)
+        if self._u0_frame is not None:                               # :535-572
+            if np.isnan(self.kappa) or self.kappa == 1:
+                raise MMCError(-1, "u0_frame/w0_frame need the infimal-convolution model (kappa not 1, not NaN)")
+            s.set_fixed_frame(self._u0_frame, self._w0_frame)
         s.init()                                                     # masks, h (:431-437), step sizes
         self._h = s.h
         if self.verbose > 0:

@@ -127,6 +127,18 @@ class FrameBlockSolver(object):
             w = None
         self._check(self._lib.mmc_set_state(self._h, fptr(u), fptr(w)))
 
+    def set_fixed_frame(self, u0, w0):
+        """Pin frame 0 of the sequence to (u0, w0); (None, None) removes the constraint."""
+        if u0 is None and w0 is None:
+            self._check(self._lib.mmc_set_fixed_frame(self._h, None, None))
+            return
+        a = None if u0 is None else as_f32(u0)
+        b = None if w0 is None else as_f32(w0)
+        for x in (a, b):
+            if x is not None and x.shape != (self.Ny, self.Nx):
+                raise ValueError("fixed frame must be %s" % ((self.Ny, self.Nx),))
+        self._check(self._lib.mmc_set_fixed_frame(self._h, fptr(a), fptr(b)))
+
     def init(self):
         self._check(self._lib.mmc_init(self._h))
 

@@ -116,3 +116,14 @@ def test_synthetic_blocks_are_slices_of_the_whole_sequence():
     warped = (W @ g1.ravel(order="F")).reshape(48, 64, order="F")
     valid = np.asarray(W.sum(axis=1)).ravel().reshape(48, 64, order="F") > 0
     assert np.median(np.abs(warped - g0)[valid]) < 5e-3
+
+
+def test_video_batch_ranges_follow_the_reference_script():
+    from superresolution_amd.video import batch_ranges
+    # variants/VideoProcessor_supplementary_MMC.m:102-107, :127, :136 (1-based there)
+    assert batch_ranges(10, 4) == [(0, 4), (3, 7), (6, 10), (8, 10)]      # batchEnd = 4*3-10 = 2: the last 2 frames again
+    assert batch_ranges(7, 4) == [(0, 4), (3, 7), (5, 7)]
+    assert batch_ranges(9, 4) == [(0, 4), (3, 7), (5, 9)]
+    assert batch_ranges(12, 5) == [(0, 5), (4, 9), (7, 12)]
+    with pytest.raises(ValueError):
+        batch_ranges(5, 1)
