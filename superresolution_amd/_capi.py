@@ -102,6 +102,13 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise ImportError("libmmc_hip.so not found at %s -- build it with "
                           "`python -m superresolution_amd.build` (there is no CPU fallback)" % path)
+    # One process can hold one HIP runtime.  PyTorch-ROCm ships its own copy under the same
+    # SONAME; loaded after the system one it finds no GPU.  Streams and device pointers are
+    # shared with torch (sharding, bench), so let torch bring in the runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is missing

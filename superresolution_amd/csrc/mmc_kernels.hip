@@ -359,7 +359,13 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
 
     // This thread's row quad.  Its own loads are issued first: they do not
     // depend on the scatter below and stay in flight across the barriers.
-    const int rq = tid & (TILE_R / 4 - 1), lc = tid / (TILE_R / 4);
+    // With zoom 4 the columns of one wave are taken 4 apart, so that the column phase of the
+    // composite kernel (c mod 4) is the same in all 64 lanes and its weights can be scalar loads.
+    constexpr int QPC = TILE_R / 4;                                   // quads per tile column
+    constexpr int CPW = 64 / QPC;                                     // tile columns per wave
+    constexpr bool PHASED = F == 4 && QPC <= 64 && CPW >= 1 && TILE_C == 4 * CPW && MMC_THREADS == 256;
+    const int rq = tid & (QPC - 1);
+    const int lc = PHASED ? ((tid / QPC) % CPW) * 4 + (tid >> 6) : tid / QPC;
     const int r = r0 + 4 * rq, c = c0 + lc;
     const bool active = r < g.Ny && c < g.Nx;
     const int j = active ? r + g.Ny * c : 0;
@@ -522,6 +528,21 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             const int xc = c - g.ox;
             const int Chi = xc / f, bc = xc - f * Chi;
             const bool cborder = !cl || !cr;
+            const bool j33 = g.Jr == 3 && g.Jc == 3;
+            // The reference's default geometry (zoom 4, 7x7 blur: oy = ox = -3): kernel row phase and
+            // low-res row of quad row i are fixed (x = r+i+3: phases 3,0,1,2; rows a,a+1,a+1,a+1 with
+            // a = r/4), so the 4 x 3 low-res values sit in registers and the weights are scalars.
+            const bool fast77 = PHASED && j33 && g.oy == -3 && g.ox == -3 && !(g.dbg & 2048);
+            float pv[4][3];
+            const float *wk = a.ckp;
+            if (fast77) {
+                const float *plb = pl + rq + g.PR * (Chi - Cbase);          // low-res rows a-2 .. a+1
+#pragma unroll
+                for (int jc = 0; jc < 3; ++jc)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pv[k][jc] = plb[k - g.PR * jc];
+                wk = a.ckp + 12 * __builtin_amdgcn_readfirstlane(bc);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ri = r + i;
@@ -529,15 +550,33 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
                     ATp[i] = 0.f;
                 } else if (cborder || ri == 0 || ri == g.Ny - 1) {
                     ATp[i] = gather_ATp(g, a.cker, p, ri, c);
+                } else if (fast77) {
+                    const int br = (i + 3) & 3, dR = (i + 3) >> 2;
+                    float s = 0.f;
+#pragma unroll
+                    for (int jc = 0; jc < 3; ++jc)
+#pragma unroll
+                        for (int jr = 0; jr < 3; ++jr)
+                            s += wk[br + 4 * jr + 48 * jc] * pv[dR - jr + 2][jc];
+                    ATp[i] = s;
                 } else {
                     const int x = ri - g.oy;
                     const int Rhi = x / f, br = x - f * Rhi;
                     const float *ck0 = ckp + br + g.MP * bc;
                     const float *pl0 = pl + (Rhi - Rbase) + g.PR * (Chi - Cbase);
                     float s = 0.f;
-                    for (int jc = 0; jc < g.Jc; ++jc)
-                        for (int jr = 0; jr < g.Jr; ++jr)
-                            s += ck0[f * jr + g.MP * f * jc] * pl0[-jr - g.PR * jc];
+                    if (F == 4 && j33) {
+                        // 3 x 3 low-res taps (7x7 or 9x9 blur at zoom 4): MP = 12, fully unrolled
+#pragma unroll
+                        for (int jc = 0; jc < 3; ++jc)
+#pragma unroll
+                            for (int jr = 0; jr < 3; ++jr)
+                                s += ck0[4 * jr + 48 * jc] * pl0[-jr - g.PR * jc];
+                    } else {
+                        for (int jc = 0; jc < g.Jc; ++jc)
+                            for (int jr = 0; jr < g.Jr; ++jr)
+                                s += ck0[f * jr + g.MP * f * jc] * pl0[-jr - g.PR * jc];
+                    }
                     ATp[i] = s;
                 }
             }
