@@ -82,6 +82,25 @@ def cpu_baseline(args, budget_s):
                       % (4 * ny, 4 * nx, nc, iters)}
 
 
+def measured_traffic(kernel, model, L, Ny, Nx):
+    """HBM bytes per launch of `kernel` from the committed hardware-counter summary
+    (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes over this same workload;
+    FETCH_SIZE doubled as gfx950 needs).  None when the summary is for another workload."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_bytes.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    wl = d.get("workload", {})
+    if wl.get("frames") != L or wl.get("hr") != [Ny, Nx] or wl.get("model") != model:
+        return None
+    for name, v in d.get("kernels", {}).items():
+        if name.startswith(kernel + "<") and ", false," in name:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -200,7 +219,9 @@ def main():
             ms, bpp = kernels[name]
             achieved = bpp * M_local / (ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK / 1e9,
-                               "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                               "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9),
+                               "traffic": measured_traffic(name, model, L, Ny, Nx),
+                               "traffic_source": "profiles/r1_pmc_hbm_bytes.json (rocprofv3 --pmc, bytes per launch)",
                                "algorithmic_bytes_per_launch": bpp * M_local, "avg_launch_ms": ms,
                                "launches_timed": prof["iterations"],
                                "all_kernels_ms": {k: v[0] for k, v in kernels.items()}}

@@ -81,17 +81,18 @@ __device__ __forceinline__ float sample(const Taps &t, const float *img) {
 // not depend on arrival order (runs are bitwise reproducible), and 2^-40 is far
 // below float32 resolution for any |value| < 2^23.
 typedef unsigned long long fx64;
-__device__ __forceinline__ fx64 to_fx(float x) {
-    const float t = x * 256.f;                      // exact
-    const float hi = floorf(t);
-    const unsigned lo = (unsigned)((t - hi) * 4294967296.f);
-    return ((fx64)(unsigned)(int)hi << 32) | (fx64)lo;
+// round(w * s40) as a two's-complement integer, |w * s40| < 2^51: adding 1.5*2^52 in double
+// leaves the integer in the mantissa, so the bit pattern minus that of 1.5*2^52 is the result.
+__device__ __forceinline__ fx64 to_fx(double w, double s40) {
+    const double d = __fma_rn(w, s40, 6755399441055744.0);
+    return (fx64)(__double_as_longlong(d) - 0x4338000000000000ll);
 }
+__device__ __forceinline__ double fx_scaled(float s) { return (double)s * 1099511627776.0; }
 __device__ __forceinline__ float from_fx(fx64 v) {
     const double d = (double)(int)(unsigned)(v >> 32) * 4294967296.0 + (double)(unsigned)(v & 0xffffffffull);
     return (float)(d * (1.0 / 1099511627776.0));
 }
-__device__ __forceinline__ void fx_add(fx64 *acc, float x) { atomicAdd(acc, to_fx(x)); }
+__device__ __forceinline__ void fx_add(fx64 *acc, float w, double s40) { atomicAdd(acc, to_fx((double)w, s40)); }
 
 // The same interpolation from an LDS copy of the rows [rlo, rlo+WR) x columns [clo, ...) of the frame.
 __device__ __forceinline__ float sample_lds(const Taps &t, const float *img, int rlo, int clo, int WR) {
@@ -234,13 +235,14 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
                 const float s1 = s1p[j];
                 float s2 = 0.f;
                 if (MODEL == MODEL_IC) s2 = kap * s2p[j] - s1;
+                const double d1 = fx_scaled(s1), d2 = fx_scaled(s2);
                 const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
                 const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
                 const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
-                if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00 * s2); }
-                if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10 * s2); }
-                if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01 * s2); }
-                if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11 * s2); }
+                if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00, d2); }
+                if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10, d2); }
+                if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01, d2); }
+                if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11, d2); }
             }
         }
         __syncthreads();
@@ -460,14 +462,15 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
                     if (!tp.valid) continue;
                     const float s1 = fs1[k];
                     const float s2 = (MODEL == MODEL_IC) ? kap * fs2[k] - s1 : 0.f;
+                    const double d1 = fx_scaled(s1), d2 = fx_scaled(s2);
                     const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
                     const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
                     const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
-                    if (g.dbg & 2) { if (s1 == 12345.f && ra0 && cb1) acc1[0] = to_fx(s2); continue; }
-                    if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00 * s2); }
-                    if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10 * s2); }
-                    if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01 * s2); }
-                    if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11 * s1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11 * s2); }
+                    if (g.dbg & 2) { if (s1 == 12345.f && ra0 && cb1) acc1[0] = to_fx(1.0, d2); continue; }
+                    if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00, d2); }
+                    if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10, d2); }
+                    if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01, d2); }
+                    if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11, d2); }
                 }
             }
         }
@@ -1104,10 +1107,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_init_scatter(Geom g, Arrays a, 
     const int r = j % g.Ny, c = j / g.Ny;
     Taps tp = make_taps(g, r, c, FR(a.vx, q)[j], FR(a.vy, q)[j]);
     if (!tp.valid) return;
-    atomicAdd(&tmp[tp.i00], to_fx(tp.w00));
-    atomicAdd(&tmp[tp.i10], to_fx(tp.w10));
-    atomicAdd(&tmp[tp.i01], to_fx(tp.w01));
-    atomicAdd(&tmp[tp.i11], to_fx(tp.w11));
+    atomicAdd(&tmp[tp.i00], to_fx((double)tp.w00, 1099511627776.0));
+    atomicAdd(&tmp[tp.i10], to_fx((double)tp.w10, 1099511627776.0));
+    atomicAdd(&tmp[tp.i01], to_fx((double)tp.w01, 1099511627776.0));
+    atomicAdd(&tmp[tp.i11], to_fx((double)tp.w11, 1099511627776.0));
     int *bb = a.bbox + (size_t)(q + 1) * g.ntiles * 4;
     const int tr0 = tp.r0 / TILE_R, tr1 = tp.r1 / TILE_R, tc0 = tp.c0 / TILE_C, tc1 = tp.c1 / TILE_C;
 #pragma unroll
