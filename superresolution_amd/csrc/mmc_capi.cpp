@@ -146,6 +146,13 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     g.tiles_r = (g.Ny + TILE_R - 1) / TILE_R;
     g.tiles_c = (g.Nx + TILE_C - 1) / TILE_C;
     g.ntiles = g.tiles_r * g.tiles_c;
+    {
+        const int q = (g.ntiles + 7) / 8;
+        const int full = g.ntiles / q, rest = g.ntiles - full * q;     // classes 0..full-1 hold q tiles, class `full` the rest
+        g.dv_tiles_r = make_fastdiv((unsigned)g.tiles_r);
+        g.dv_q = make_fastdiv((unsigned)q);
+        g.dv_qlast = make_fastdiv((unsigned)(rest > 0 ? rest : q));
+    }
     g.inv_h = 1.f;
     if (const char *e = getenv("MMC_DEBUG")) g.dbg = atoi(e);
     if (p->h > 0.f) { h->h = p->h; h->have_h = true; g.inv_h = 1.f / p->h; }
@@ -317,6 +324,7 @@ static int build_data_operator(mmc_handle *h) {
     g.Jr = (g.CH + g.f - 1) / g.f; g.Jc = (g.CW + g.f - 1) / g.f;
     g.MP = g.f * g.Jr; g.NP = g.f * g.Jc;
     g.PR = (TILE_R - 1) / g.f + g.Jr + 1; g.PC = (TILE_C - 1) / g.f + g.Jc + 1;
+    g.dv_PR = make_fastdiv((unsigned)g.PR);
     std::vector<float> ckpad((size_t)g.MP * g.NP, 0.f);
     for (int nn = 0; nn < g.CW; ++nn)
         for (int mm = 0; mm < g.CH; ++mm) ckpad[(size_t)mm + (size_t)g.MP * nn] = ckf[(size_t)mm + (size_t)g.CH * nn];

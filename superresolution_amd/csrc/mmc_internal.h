@@ -24,6 +24,19 @@ enum { MMC_WARP_MAX = 2304 }; // floats of the warped frame a tile may stage in 
 enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
 enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device
 
+// Division of 0 <= n < 2^31 by a fixed d through one high multiply: n / d = umulhi(n, m) >> s
+// with m = ceil(2^(31+l) / d), s = l - 1, l = ceil(log2 d); d = 1 is flagged by m = 0.
+struct FastDiv { unsigned m, s; };
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv r = {0u, 0u};
+    if (d <= 1u) return r;
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;
+    r.m = (unsigned)((((uint64_t)1 << (31 + l)) + d - 1) / d);
+    r.s = l - 1;
+    return r;
+}
+
 struct Geom {
     int Ny, Nx, N;             // high-resolution frame
     int ny, nx, n;             // low-resolution frame
@@ -37,6 +50,9 @@ struct Geom {
     int MP, NP;                // zero-padded composite kernel table: f*Jr x f*Jc
     int PR, PC;                // low-res window staged per tile
     int tiles_r, tiles_c, ntiles;
+    FastDiv dv_tiles_r;        // tile -> (tile row, tile column)
+    FastDiv dv_q, dv_qlast;    // tiles per XCD class ((ntiles+7)/8) and of the last non-empty class
+    FastDiv dv_PR;
     float alpha, kappa, inv_h;
     float radius1, radius2;    // projection radii of the g1 / g2 groups
     int fixed;                 // 1: first frame of the sequence is pinned to (u0, w0), MultiframeMotionCoupling.m:535-572

@@ -80,6 +80,20 @@ __device__ __forceinline__ float sample(const Taps &t, const float *img) {
 // gfx950 whereas float LDS atomics take about 3 clocks per lane, integer sums do
 // not depend on arrival order (runs are bitwise reproducible), and 2^-40 is far
 // below float32 resolution for any |value| < 2^23.
+#ifndef MMC_SCU
+#define MMC_SCU 5
+#endif
+#ifndef MMC_FAST77
+#define MMC_FAST77 1
+#endif
+#ifndef MMC_LATE
+#define MMC_LATE 1
+#endif
+#ifndef MMC_P_WAVES
+#define MMC_P_ATTR
+#else
+#define MMC_P_ATTR __attribute__((amdgpu_waves_per_eu(MMC_P_WAVES, MMC_P_WAVES)))
+#endif
 typedef unsigned long long fx64;
 // round(w * s40) as a two's-complement integer, |w * s40| < 2^51: adding 1.5*2^52 in double
 // leaves the integer in the mantissa, so the bit pattern minus that of 1.5*2^52 is the result.
@@ -100,6 +114,14 @@ __device__ __forceinline__ float sample_lds(const Taps &t, const float *img, int
     const int dr = t.r1 - t.r0, dc = (t.c1 - t.c0) * WR;
     return t.w00 * img[i0] + t.w10 * img[i0 + dr] + t.w01 * img[i0 + dc] + t.w11 * img[i0 + dr + dc];
 }
+
+__device__ __forceinline__ int fdiv(int n, FastDiv d) { return d.m ? (int)(__umulhi((unsigned)n, d.m) >> d.s) : n; }
+// Hardware reciprocal and reciprocal square root (1 ulp) in place of the correctly rounded
+// division / sqrt sequences: step sizes and projection scales do not need the last bit.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+// Scale that projects a vector of squared length n2 onto the ball of radius R.
+__device__ __forceinline__ float ball_scale(float n2, float R) { return n2 > R * R ? R * fast_rsq(n2) : 1.f; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -145,7 +167,7 @@ __device__ __forceinline__ bool decode_block(const Geom &g, int nf, int &tile, i
     const int q = (g.ntiles + 7) >> 3;
     const int lo = x * q, cnt = min(q, g.ntiles - lo);
     if (cnt <= 0 || s >= cnt * nf) return false;
-    trel = s / cnt;
+    trel = fdiv(s, cnt == q ? g.dv_q : g.dv_qlast);
     tile = lo + (s - trel * cnt);
     return true;
 }
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
     __shared__ fx64 acc2[TILE_R * TILE_C];
     const int t = t0 + blockIdx.y;
     const int tile = blockIdx.x;
-    const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
     const int r0 = tr * TILE_R, c0 = tc * TILE_C;
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
 
@@ -271,10 +293,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
         float tau_u, tau_w = 0.f;
         const bool isfix = MODEL == MODEL_IC && g.fixed && g.frame_begin + t == 0;   // identity rows of q1, q2 (:560-561)
         if (MODEL == MODEL_IC) {
-            tau_u = 1.f / (a.cA[j] + cw + kap * cgrad + (isfix ? 1.f : 0.f));
-            tau_w = 1.f / ((1.f + kap) * (cw + cgrad) + (isfix ? 1.f : 0.f));
+            tau_u = fast_rcp(a.cA[j] + cw + kap * cgrad + (isfix ? 1.f : 0.f));
+            tau_w = fast_rcp((1.f + kap) * (cw + cgrad) + (isfix ? 1.f : 0.f));
         } else {
-            tau_u = 1.f / (a.cA[j] + cw + cgrad);
+            tau_u = fast_rcp(a.cA[j] + cw + cgrad);
         }
         if (MODE == MODE_STEPS) {
             ub[j] = tau_u;
@@ -341,7 +363,7 @@ __device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
 }
 
 template <int MODEL, int MODE, bool REDUCE, int F>
-__global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t0, int nf) {
+__global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     fx64 *acc1 = reinterpret_cast<fx64 *>(lds);
     fx64 *acc2 = acc1 + TILE_R * TILE_C;
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     int tile, trel;
     if (!decode_block(g, nf, tile, trel)) return;
     const int t = t0 + trel;
-    const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
     const int r0 = tr * TILE_R, c0 = tc * TILE_C;
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
     const float *p = a.p + (size_t)t * g.n;
@@ -378,32 +400,40 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     float gx1[4], gl1[4] = {0.f, 0.f, 0.f, 0.f}, gy1[4], up1 = 0.f;
     float gx2[4], gl2[4] = {0.f, 0.f, 0.f, 0.f}, gy2[4], up2 = 0.f;
     float sA1[4] = {0.f, 0.f, 0.f, 0.f}, sA2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (active) {
-        ld4(cWv, FR(a.cW, t) + j);
-        ld4(cAv, a.cA + j);
-        if (MODE == MODE_UPDATE) {
-            ld4(uo, FR(a.u, t) + j);
-            if (MODEL == MODEL_IC) ld4(wo, FR(a.w, t) + j);
+    // Loads of this thread's own quad, in four groups.  A group is issued either here, ahead of the
+    // scatter (it then occupies its registers across the scatter), or after it.
+    auto own_loads = [&](bool grpX, bool grpA, bool grp2, bool grp1) {
+        if (!active) return;
+        if (grpX) {
+            ld4(cWv, FR(a.cW, t) + j);
+            ld4(cAv, a.cA + j);
+            if (MODE == MODE_UPDATE) {
+                ld4(uo, FR(a.u, t) + j);
+                if (MODEL == MODEL_IC) ld4(wo, FR(a.w, t) + j);
+            }
         }
-        if (MODE != MODE_STEPS) {
+        if (MODE == MODE_STEPS) return;
+        if (grp1) {
             const float *g1x = FR(a.g1x, t) + j, *g1y = FR(a.g1y, t) + j;
             ld4(gx1, g1x);
             if (cl) ld4(gl1, g1x - g.Ny);
             ld4(gy1, g1y);
             if (r > 0) up1 = g1y[-1];
-            if (MODEL == MODEL_IC) {
-                const float *g2x = FR(a.g2x, t) + j, *g2y = FR(a.g2y, t) + j;
-                ld4(gx2, g2x);
-                if (cl) ld4(gl2, g2x - g.Ny);
-                ld4(gy2, g2y);
-                if (r > 0) up2 = g2y[-1];
-            }
-            if (idA) {
-                ld4(sA1, FR(a.g1t, t) + j);
-                if (MODEL == MODEL_IC) ld4(sA2, FR(a.g2t, t) + j);
-            }
         }
-    }
+        if (grp2 && MODEL == MODEL_IC) {
+            const float *g2x = FR(a.g2x, t) + j, *g2y = FR(a.g2y, t) + j;
+            ld4(gx2, g2x);
+            if (cl) ld4(gl2, g2x - g.Ny);
+            ld4(gy2, g2y);
+            if (r > 0) up2 = g2y[-1];
+        }
+        if (grpA && idA) {
+            ld4(sA1, FR(a.g1t, t) + j);
+            if (MODEL == MODEL_IC) ld4(sA2, FR(a.g2t, t) + j);
+        }
+    };
+    constexpr int LATE = MMC_LATE;
+    own_loads(LATE < 1, LATE < 2, LATE < 3, LATE < 4);
 
     for (int k = tid; k < TILE_R * TILE_C; k += MMC_THREADS) {
         acc1[k] = 0;
@@ -412,7 +442,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     if (MODE != MODE_STEPS) {
         for (int k = tid; k < g.MP * g.NP; k += MMC_THREADS) ckp[k] = a.ckp[k];
         for (int k = tid; k < g.PR * g.PC; k += MMC_THREADS) {
-            const int pc = k / g.PR, pr = k - pc * g.PR;
+            const int pc = fdiv(k, g.dv_PR), pr = k - pc * g.PR;
             const int R = Rbase + pr, C = Cbase + pc;
             pl[k] = (R >= 0 && R < g.ny && C >= 0 && C < g.nx) ? p[R + g.ny * C] : 0.f;
         }
@@ -423,7 +453,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     // SCU source pixels per thread and pass, all their loads issued before the
     // first use so that one pass costs one memory round trip.
     if (MODE != MODE_STEPS) {
-        constexpr int SCU = 5;
+        constexpr int SCU = MMC_SCU;
         for (int which = 0; which < 2; ++which) {
             const int q = which == 0 ? t - 1 : t;
             if (!pair_exists(g, q)) continue;
@@ -434,7 +464,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             if (rmax < rmin || cmax < cmin) continue;
             if (g.dbg & 1) continue;
             const int nr = rmax - rmin + 1, total = nr * (cmax - cmin + 1);
-            const float inv_nr = 1.f / (float)nr;
+            const float inv_nr = fast_rcp((float)nr);
             const float *vx = FR(a.vx, q), *vy = FR(a.vy, q);
             const float *s1p = FR(a.g1t, q), *s2p = FR(a.g2t, q);
             for (int base = tid; base < total; base += MMC_THREADS * SCU) {
@@ -477,6 +507,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
         __syncthreads();
     }
 
+    own_loads(LATE >= 1, LATE >= 2, LATE >= 3, LATE >= 4);
     float part[2] = {0.f, 0.f};
     if (active) {
         float *u = FR(a.u, t) + j, *w = FR(a.w, t) + j, *ub = FR(a.ub, t) + j, *wb = FR(a.wb, t) + j;
@@ -488,10 +519,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             const float cgrad = (float)((int)cl + (int)cr + (int)(r + i > 0) + (int)(r + i < g.Ny - 1));
             const float cw = cWv[i] * g.inv_h;
             if (MODEL == MODEL_IC) {
-                tau_u[i] = 1.f / (cAv[i] + cw + kap * cgrad + fixc);
-                tau_w[i] = 1.f / ((1.f + kap) * (cw + cgrad) + fixc);
+                tau_u[i] = fast_rcp(cAv[i] + cw + kap * cgrad + fixc);
+                tau_w[i] = fast_rcp((1.f + kap) * (cw + cgrad) + fixc);
             } else {
-                tau_u[i] = 1.f / (cAv[i] + cw + cgrad);
+                tau_u[i] = fast_rcp(cAv[i] + cw + cgrad);
                 tau_w[i] = 0.f;
             }
         }
@@ -535,7 +566,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             // The reference's default geometry (zoom 4, 7x7 blur: oy = ox = -3): kernel row phase and
             // low-res row of quad row i are fixed (x = r+i+3: phases 3,0,1,2; rows a,a+1,a+1,a+1 with
             // a = r/4), so the 4 x 3 low-res values sit in registers and the weights are scalars.
-            const bool fast77 = PHASED && j33 && g.oy == -3 && g.ox == -3 && !(g.dbg & 2048);
+            const bool fast77 = MMC_FAST77 && PHASED && j33 && g.oy == -3 && g.ox == -3 && !(g.dbg & 2048);
             float pv[4][3];
             const float *wk = a.ckp;
             if (fast77) {
@@ -637,7 +668,7 @@ template <int MODEL, int MODE, bool REDUCE>
 __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) {
     const int t = t0 + blockIdx.y;
     const int tile = blockIdx.x;
-    const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
     const int r0 = tr * TILE_R, c0 = tc * TILE_C;
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
     const bool pex = pair_exists(g, t);
@@ -701,8 +732,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) 
                 rs2 = fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f);
             }
         }
-        const float sg1 = rs1 > 0.f ? 1.f / rs1 : 1.f;
-        const float sg2 = rs2 > 0.f ? 1.f / rs2 : 1.f;
+        const float sg1 = rs1 > 0.f ? fast_rcp(rs1) : 1.f;
+        const float sg2 = rs2 > 0.f ? fast_rcp(rs2) : 1.f;
 
         if (MODE == MODE_RAW) {
             g1t[j] = k1t; g1x[j] = k1x; g1y[j] = k1y;
@@ -733,15 +764,15 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) 
             n1t = valid ? fminf(fmaxf(o1t + sg1 * k1t, -g.radius1), g.radius1) : 0.f;
             n1x = o1x + sg2 * k1x;
             n1y = o1y + sg2 * k1y;
-            const float nrm = sqrtf(n1x * n1x + n1y * n1y);
-            if (nrm > g.radius2) { const float sc = g.radius2 / nrm; n1x *= sc; n1y *= sc; }
+            const float sc = ball_scale(n1x * n1x + n1y * n1y, g.radius2);
+            n1x *= sc; n1y *= sc;
         } else {
             // ||(gt,gx,gy)||_2 <= radius (:497, :513)
             n1t = valid ? o1t + sg1 * k1t : 0.f;
             n1x = o1x + sg1 * k1x;
             n1y = o1y + sg1 * k1y;
-            const float nrm = sqrtf(n1t * n1t + n1x * n1x + n1y * n1y);
-            if (nrm > g.radius1) { const float sc = g.radius1 / nrm; n1t *= sc; n1x *= sc; n1y *= sc; }
+            const float sc = ball_scale(n1t * n1t + n1x * n1x + n1y * n1y, g.radius1);
+            n1t *= sc; n1x *= sc; n1y *= sc;
         }
         g1t[j] = n1t; g1x[j] = n1x; g1y[j] = n1y;
         if (REDUCE) {
@@ -753,8 +784,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) 
             float n2t = valid ? o2t + sg2 * k2t : 0.f;
             float n2x = o2x + sg2 * k2x;
             float n2y = o2y + sg2 * k2y;
-            const float nrm = sqrtf(n2t * n2t + n2x * n2x + n2y * n2y);
-            if (nrm > g.radius2) { const float sc = g.radius2 / nrm; n2t *= sc; n2x *= sc; n2y *= sc; }
+            const float sc = ball_scale(n2t * n2t + n2x * n2x + n2y * n2y, g.radius2);
+            n2t *= sc; n2x *= sc; n2y *= sc;
             g2t[j] = n2t; g2x[j] = n2x; g2y[j] = n2y;
             if (REDUCE) {
                 part[0] += (n2t - o2t) * (n2t - o2t) + (n2x - o2x) * (n2x - o2x) + (n2y - o2y) * (n2y - o2y);
@@ -833,7 +864,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     int tile, trel;
     if (!decode_block(g, nf, tile, trel)) return;
     const int t = t0 + trel;
-    const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
     const int r0 = tr * TILE_R, c0 = tc * TILE_C;
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
     const bool pex = pair_exists(g, t);
@@ -890,7 +921,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
 
     // stage the xbar_u window, replicate border (helpers/RepConvMtx.m:23-32)
     if (MODE != MODE_STEPS && !(g.dbg & 512)) {
-        const float inv_sr = 1.f / (float)SR;
+        const float inv_sr = fast_rcp((float)SR);
         for (int k = tid; k < SR * SC; k += MMC_THREADS) {
             int kc = (int)(((float)k + 0.5f) * inv_sr);
             int kr = k - kc * SR;
@@ -903,7 +934,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     }
     if (use_lds) {
         const int QR = WR >> 2, nq = QR * WC;
-        const float inv_qr = 1.f / (float)QR;
+        const float inv_qr = fast_rcp((float)QR);
         for (int k = tid; k < nq; k += MMC_THREADS) {
             int kc = (int)(((float)k + 0.5f) * inv_qr);
             int kr = k - kc * QR;
@@ -970,8 +1001,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                     rs2 = fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f);
                 }
             }
-            sg1[i] = rs1 > 0.f ? 1.f / rs1 : 1.f;
-            sg2[i] = rs2 > 0.f ? 1.f / rs2 : 1.f;
+            sg1[i] = rs1 > 0.f ? fast_rcp(rs1) : 1.f;
+            sg2[i] = rs2 > 0.f ? fast_rcp(rs2) : 1.f;
         }
         float *g1t = FR(a.g1t, t) + j, *g1x = FR(a.g1x, t) + j, *g1y = FR(a.g1y, t) + j;
         float *g2t = FR(a.g2t, t) + j, *g2x = FR(a.g2x, t) + j, *g2y = FR(a.g2y, t) + j;
@@ -1001,15 +1032,15 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                     n1t[i] = valid[i] ? fminf(fmaxf(o1t[i] + sg1[i] * k1t[i], -g.radius1), g.radius1) : 0.f;
                     n1x[i] = o1x[i] + sg2[i] * k1x[i];
                     n1y[i] = o1y[i] + sg2[i] * k1y[i];
-                    const float nrm = sqrtf(n1x[i] * n1x[i] + n1y[i] * n1y[i]);
-                    if (nrm > g.radius2) { const float sc = g.radius2 / nrm; n1x[i] *= sc; n1y[i] *= sc; }
+                    const float sc = ball_scale(n1x[i] * n1x[i] + n1y[i] * n1y[i], g.radius2);
+                    n1x[i] *= sc; n1y[i] *= sc;
                 } else {
                     // ||(gt,gx,gy)||_2 <= radius (:497, :513)
                     n1t[i] = valid[i] ? o1t[i] + sg1[i] * k1t[i] : 0.f;
                     n1x[i] = o1x[i] + sg1[i] * k1x[i];
                     n1y[i] = o1y[i] + sg1[i] * k1y[i];
-                    const float nrm = sqrtf(n1t[i] * n1t[i] + n1x[i] * n1x[i] + n1y[i] * n1y[i]);
-                    if (nrm > g.radius1) { const float sc = g.radius1 / nrm; n1t[i] *= sc; n1x[i] *= sc; n1y[i] *= sc; }
+                    const float sc = ball_scale(n1t[i] * n1t[i] + n1x[i] * n1x[i] + n1y[i] * n1y[i], g.radius1);
+                    n1t[i] *= sc; n1x[i] *= sc; n1y[i] *= sc;
                 }
                 if (REDUCE) {
                     part[0] += (n1t[i] - o1t[i]) * (n1t[i] - o1t[i]) + (n1x[i] - o1x[i]) * (n1x[i] - o1x[i]) +
@@ -1025,8 +1056,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                     n2t[i] = valid[i] ? o2t[i] + sg2[i] * k2t[i] : 0.f;
                     n2x[i] = o2x[i] + sg2[i] * k2x[i];
                     n2y[i] = o2y[i] + sg2[i] * k2y[i];
-                    const float nrm = sqrtf(n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i]);
-                    if (nrm > g.radius2) { const float sc = g.radius2 / nrm; n2t[i] *= sc; n2x[i] *= sc; n2y[i] *= sc; }
+                    const float sc = ball_scale(n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i], g.radius2);
+                    n2t[i] *= sc; n2x[i] *= sc; n2y[i] *= sc;
                     if (REDUCE) {
                         part[0] += (n2t[i] - o2t[i]) * (n2t[i] - o2t[i]) + (n2x[i] - o2x[i]) * (n2x[i] - o2x[i]) +
                                    (n2y[i] - o2y[i]) * (n2y[i] - o2y[i]);
@@ -1145,7 +1176,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_init_tapbox(Geom g, Arrays a) {
     if (threadIdx.x == 0) { box[0] = INT_MAX; box[1] = -1; box[2] = INT_MAX; box[3] = -1; }
     __syncthreads();
     if (pair_exists(g, t)) {
-        const int tr = tile % g.tiles_r, tc = tile / g.tiles_r;
+        const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
         for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) {
             const int r = tr * TILE_R + k % TILE_R, c = tc * TILE_C + k / TILE_R;
             if (r >= g.Ny || c >= g.Nx) continue;
