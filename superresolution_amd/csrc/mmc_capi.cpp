@@ -171,6 +171,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     if ((rc = dev_alloc(h, &a.cA, (size_t)g.N)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.sigp, (size_t)g.n)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.ckq, (size_t)(MMC_MAX_CK + 8) * MMC_MAX_CK)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.ckp, (size_t)(MMC_MAX_CK + p->factor) * (MMC_MAX_CK + p->factor))) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.bbox, (size_t)(h->L + 1) * g.ntiles * 4)) != MMC_OK) return bail(rc);
     { float **fx[] = {&a.q1, &a.q2, &a.u0, &a.w0}; for (float **pp : fx) if ((rc = dev_alloc(h, pp, (size_t)g.N)) != MMC_OK) return bail(rc); }
@@ -329,6 +330,13 @@ static int build_data_operator(mmc_handle *h) {
     for (int nn = 0; nn < g.CW; ++nn)
         for (int mm = 0; mm < g.CH; ++mm) ckpad[(size_t)mm + (size_t)g.MP * nn] = ckf[(size_t)mm + (size_t)g.CH * nn];
     HIPCHK(h, hipMemcpyAsync(h->a.ckp, ckpad.data(), ckpad.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    g.wpad = (4 - ((-g.oy) & 3)) & 3;
+    g.SRp = (g.wpad + TILE_R + g.CH - g.f + 3) & ~3;
+    g.MPq = (g.wpad + g.CH + 3) & ~3;
+    std::vector<float> ckq((size_t)g.MPq * g.CW, 0.f);
+    for (int nn = 0; nn < g.CW; ++nn)
+        for (int mm = 0; mm < g.CH; ++mm) ckq[(size_t)(g.wpad + mm) + (size_t)g.MPq * nn] = ckf[(size_t)mm + (size_t)g.CH * nn];
+    HIPCHK(h, hipMemcpyAsync(h->a.ckq, ckq.data(), ckq.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<double> colsum((size_t)g.N, 0.0);
     std::vector<float> sig((size_t)g.n);

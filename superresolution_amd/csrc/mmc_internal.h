@@ -17,7 +17,10 @@ enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3 };
 #ifndef MMC_TILE_C
 #define MMC_TILE_C 16
 #endif
-enum { TILE_R = MMC_TILE_R, TILE_C = MMC_TILE_C, MMC_THREADS = 256 };
+#ifndef MMC_NTHREADS
+#define MMC_NTHREADS 256
+#endif
+enum { TILE_R = MMC_TILE_R, TILE_C = MMC_TILE_C, MMC_THREADS = MMC_NTHREADS };
 static_assert(TILE_R * TILE_C == 4 * MMC_THREADS && (TILE_R & (TILE_R - 1)) == 0, "tile must hold one row quad per thread");
 enum { MMC_MAX_CK = 24 };      // max side of the composite (sampling * blur) kernel
 enum { MMC_WARP_MAX = 2304 }; // floats of the warped frame a tile may stage in LDS per plane
@@ -49,6 +52,8 @@ struct Geom {
     int Jr, Jc;                // low-res taps per axis of the adjoint: ceil(CH/f), ceil(CW/f)
     int MP, NP;                // zero-padded composite kernel table: f*Jr x f*Jc
     int PR, PC;                // low-res window staged per tile
+    int wpad, SRp, MPq;        // dual sweep, zoom 4: rows added above the xbar window so that it starts on a row quad,
+                               // its padded height (multiple of 4), and the height of the kernel table shifted by wpad
     int tiles_r, tiles_c, ntiles;
     FastDiv dv_tiles_r;        // tile -> (tile row, tile column)
     FastDiv dv_q, dv_qlast;    // tiles per XCD class ((ntiles+7)/8) and of the last non-empty class
@@ -76,6 +81,7 @@ struct Arrays {
     float *sigp;               // 1 / row abs-sum of D*B, n
     float *cker;               // composite kernel, CH x CW column-major
     float *ckp;                // the same, zero-padded to MP x NP
+    float *ckq;                // the same, wpad zero rows on top, zero-padded to MPq x CW
     int *bbox;                 // [(L+1) pair slots][ntiles][4] = rmin,rmax,cmin,cmax of the SOURCES of a tile
     int *tbox;                 // [L pair slots][ntiles][4] = rows/cols of the warped frame a tile's TAPS touch
     double *sums;              // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]

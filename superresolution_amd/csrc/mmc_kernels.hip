@@ -869,11 +869,17 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
     const bool pex = pair_exists(g, t);
     const bool isIF = pair_is_IF(g, t);
-    const int SR = TILE_R + g.CH - f, SC = TILE_C + g.CW - f;
+    // Zoom 4: the window starts on a row quad (g.wpad extra rows on top, height g.SRp), so that it
+    // is staged with 16-byte loads and each low-res pixel reads its kernel rows as aligned float4.
+    const bool VEC = F == 4 && g.SRp <= 128 && !(g.dbg & 4096);
+    const int SR = VEC ? g.SRp : TILE_R + g.CH - f, SC = TILE_C + g.CW - f;
+    const int wpad = VEC ? g.wpad : 0;
     const int LRR = TILE_R / f, LRC = TILE_C / f, nlr = LRR * LRC;
-    float *ubl = lds;                   // SR x SC window of xbar_u
-    float *psum = lds + SR * SC;        // [4 waves][nlr] partial sums of A xbar_u
-    float *wu = lds + ((SR * SC + 4 * nlr + 3) & ~3);   // tap region of the warped frame, xbar_u
+    constexpr int NWV = MMC_THREADS / 64;
+    float *ubl = lds;                                   // SR x SC window of xbar_u
+    float *psum = lds + ((SR * SC + 3) & ~3);           // [NWV waves][nlr] partial sums of A xbar_u
+    float *ckq = psum + ((NWV * nlr + 3) & ~3);         // composite kernel shifted down by wpad rows, MPq x CW
+    float *wu = ckq + g.MPq * g.CW;                     // tap region of the warped frame, xbar_u
     float *ww = wu + MMC_WARP_MAX;                      // ... and xbar_w
     const float *ub = FR(a.ub, t), *wb = FR(a.wb, t);
     const float *ubW = FR(a.ub, isIF ? t + 1 : t), *wbW = FR(a.wb, isIF ? t + 1 : t);   // warped frame
@@ -921,15 +927,28 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
 
     // stage the xbar_u window, replicate border (helpers/RepConvMtx.m:23-32)
     if (MODE != MODE_STEPS && !(g.dbg & 512)) {
-        const float inv_sr = fast_rcp((float)SR);
-        for (int k = tid; k < SR * SC; k += MMC_THREADS) {
-            int kc = (int)(((float)k + 0.5f) * inv_sr);
-            int kr = k - kc * SR;
-            if (kr < 0) { --kc; kr += SR; }
-            if (kr >= SR) { ++kc; kr -= SR; }
-            const int rr = min(max(r0 + g.oy + kr, 0), g.Ny - 1);
-            const int cc = min(max(c0 + g.ox + kc, 0), g.Nx - 1);
-            ubl[k] = ub[rr + g.Ny * cc];
+        const int wr0 = r0 + g.oy - wpad, wc0 = c0 + g.ox;
+        if (VEC) {
+            for (int k = tid; k < g.MPq * g.CW; k += MMC_THREADS) ckq[k] = a.ckq[k];
+        }
+        if (VEC && wr0 >= 0 && wr0 + SR <= g.Ny && wc0 >= 0 && wc0 + SC <= g.Nx) {
+            const int kq = tid & 31;            // SR <= 128: at most 32 quads per window column
+            if (4 * kq < SR) {
+                const float *src = ub + wr0 + 4 * kq + g.Ny * wc0;
+                for (int kc = tid >> 5; kc < SC; kc += MMC_THREADS / 32)
+                    *reinterpret_cast<float4 *>(ubl + 4 * kq + SR * kc) = *reinterpret_cast<const float4 *>(src + g.Ny * kc);
+            }
+        } else {
+            const float inv_sr = fast_rcp((float)SR);
+            for (int k = tid; k < SR * SC; k += MMC_THREADS) {
+                int kc = (int)(((float)k + 0.5f) * inv_sr);
+                int kr = k - kc * SR;
+                if (kr < 0) { --kc; kr += SR; }
+                if (kr >= SR) { ++kc; kr -= SR; }
+                const int rr = min(max(wr0 + kr, 0), g.Ny - 1);
+                const int cc = min(max(wc0 + kc, 0), g.Nx - 1);
+                ubl[k] = ub[rr + g.Ny * cc];
+            }
         }
     }
     if (use_lds) {
@@ -1087,14 +1106,27 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     // ---- data term: p <- clamp(p + s (A xbar_u - f), -1, 1)   (:496) --------
     float epart = 0.f;
     if (MODE != MODE_STEPS && !(g.dbg & 512)) {
-        const int wv = tid >> 6, lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         for (int lp = lane; lp < nlr; lp += 64) {
             const int Rl = lp % LRR, Cl = lp / LRR;
             float s = 0.f;
-            for (int nn = wv; nn < g.CW; nn += MMC_THREADS / 64) {
-                const float *col = ubl + f * Rl + SR * (f * Cl + nn);
-                const float *ck = a.cker + g.CH * nn;
-                for (int mm = 0; mm < g.CH; ++mm) s += ck[mm] * col[mm];
+            if (VEC) {
+                // lanes are 16 bytes apart (conflict-free), the kernel rows are a broadcast
+                const int mq = g.MPq >> 2;
+                for (int nn = wv; nn < g.CW; nn += NWV) {
+                    const float4 *col = reinterpret_cast<const float4 *>(ubl + f * Rl + SR * (f * Cl + nn));
+                    const float4 *ck = reinterpret_cast<const float4 *>(ckq + g.MPq * nn);
+                    for (int m4 = 0; m4 < mq; ++m4) {
+                        const float4 cv = ck[m4], dv = col[m4];
+                        s += cv.x * dv.x + cv.y * dv.y + cv.z * dv.z + cv.w * dv.w;
+                    }
+                }
+            } else {
+                for (int nn = wv; nn < g.CW; nn += NWV) {
+                    const float *col = ubl + f * Rl + SR * (f * Cl + nn);
+                    const float *ck = a.cker + g.CH * nn;
+                    for (int mm = 0; mm < g.CH; ++mm) s += ck[mm] * col[mm];
+                }
             }
             psum[wv * nlr + lp] = s;
         }
@@ -1108,7 +1140,9 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
         const size_t o = (size_t)t * g.n + i;
         const float sg = a.sigp[i];
         if (MODE == MODE_STEPS) { a.p[o] = sg; continue; }
-        const float acc = psum[lp] + psum[nlr + lp] + psum[2 * nlr + lp] + psum[3 * nlr + lp];
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < MMC_THREADS / 64; ++k) acc += psum[k * nlr + lp];
         if (MODE == MODE_RAW) {
             a.p[o] = acc;
         } else if (MODE == MODE_ENERGY) {
@@ -1291,8 +1325,9 @@ template <int MODEL, int F>
 static void launch_dual4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const int f = g.f;
-    const size_t lds = (size_t)((((TILE_R + g.CH - f) * (TILE_C + g.CW - f) + 4 * (TILE_R / f) * (TILE_C / f) + 3) & ~3) +
-                                2 * MMC_WARP_MAX) * sizeof(float);
+    const int SRmax = g.SRp > TILE_R + g.CH - f ? g.SRp : TILE_R + g.CH - f;
+    const size_t lds = (size_t)(((SRmax * (TILE_C + g.CW - f) + 3) & ~3) + (((MMC_THREADS / 64) * (TILE_R / f) * (TILE_C / f) + 3) & ~3) +
+                                g.MPq * g.CW + 2 * MMC_WARP_MAX) * sizeof(float);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F>), grid, block, lds, s, g, a, t0, nf);
