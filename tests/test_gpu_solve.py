@@ -72,3 +72,23 @@ def test_energy_decreases_and_tolerance_stop():
     assert max(st["res_primal"], st["res_dual"]) < 1e-4
     assert [it for it, _ in seen] == list(range(50, st["iterations"] + 1, 50))
     s.close()
+
+
+@pytest.mark.parametrize("kappa", [0.25, float("nan")])
+def test_solve_parity_interior_tiles(kappa):
+    """A frame of 192x112 HR pixels has workgroup tiles (64x16) whose blur window, low-res ring and
+    warp tap region lie wholly inside the image, i.e. the vectorised interior paths of both sweeps,
+    next to border tiles and a ragged last tile column."""
+    f, v, occ = make_case(31, 48, 28, 3, flow="smooth", flow_scale=1.5, with_occ=True)
+    P, x, chg, u_ref, w_ref, u, w, st, e = _run(f, v, occ, kappa, "backward", 60)
+    assert rel_l2(u, u_ref) < TOL
+    e_ref = orc.primal_energy(P, x)
+    assert abs(e - e_ref) <= 1e-3 * abs(e_ref)
+
+
+def test_solve_parity_violent_flow():
+    """Flow of +-12 pixels per frame, random per pixel: tap regions and source boxes outgrow what a
+    tile stages on chip, so the global-memory gather and multi-pass scatter run."""
+    f, v, occ = make_case(32, 40, 24, 3, flow="random", flow_scale=12.0)
+    P, x, chg, u_ref, w_ref, u, w, st, e = _run(f, v, occ, 0.25, "forward-backward", 40)
+    assert rel_l2(u, u_ref) < TOL
