@@ -324,7 +324,14 @@ static int build_data_operator(mmc_handle *h) {
     std::vector<float> ckf(ck.begin(), ck.end());
     g.Jr = (g.CH + g.f - 1) / g.f; g.Jc = (g.CW + g.f - 1) / g.f;
     g.MP = g.f * g.Jr; g.NP = g.f * g.Jc;
-    g.PR = (TILE_R - 1) / g.f + g.Jr + 1; g.PC = (TILE_C - 1) / g.f + g.Jc + 1;
+    // Low-res window of p staged per tile by the primal sweep.  Border tiles also evaluate the virtual
+    // rows / columns outside the frame that the replicate border folds onto the first and last pixel.
+    {
+        const int er = std::max(g.f * (g.ny - 1) + g.oy + g.CH - 1 - (g.Ny - 1), 0);
+        const int ec = std::max(g.f * (g.nx - 1) + g.ox + g.CW - 1 - (g.Nx - 1), 0);
+        g.PR = (TILE_R - 1) / g.f + g.Jr + 1 + (-g.oy + g.f - 1) / g.f + (er + g.f - 1) / g.f;
+        g.PC = (TILE_C - 1) / g.f + g.Jc + 1 + (-g.ox + g.f - 1) / g.f + (ec + g.f - 1) / g.f;
+    }
     g.dv_PR = make_fastdiv((unsigned)g.PR);
     std::vector<float> ckpad((size_t)g.MP * g.NP, 0.f);
     for (int nn = 0; nn < g.CW; ++nn)

@@ -378,8 +378,10 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
     const int r0 = tr * TILE_R, c0 = tc * TILE_C;
     const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
     const float *p = a.p + (size_t)t * g.n;
-    const int Rbase = (r0 - g.oy) / f - (g.Jr - 1);
-    const int Cbase = (c0 - g.ox) / f - (g.Jc - 1);
+    // First low-res row / column of the staged window of p.  In the first tile row (column) the
+    // virtual rows above (left of) the frame start at kernel coordinate 0.
+    const int Rbase = (r0 == 0 ? 0 : (r0 - g.oy) / f) - (g.Jr - 1);
+    const int Cbase = (c0 == 0 ? 0 : (c0 - g.ox) / f) - (g.Jc - 1);
 
     // This thread's row quad.  Its own loads are issued first: they do not
     // depend on the scatter below and stay in flight across the barriers.
@@ -514,18 +516,21 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
         float tau_u[4], tau_w[4];
         const bool isfix = MODEL == MODEL_IC && g.fixed && g.frame_begin + t == 0;   // identity rows of q1, q2 (:560-561)
         const float fixc = isfix ? 1.f : 0.f;
+        auto compute_tau = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float cgrad = (float)((int)cl + (int)cr + (int)(r + i > 0) + (int)(r + i < g.Ny - 1));
-            const float cw = cWv[i] * g.inv_h;
-            if (MODEL == MODEL_IC) {
-                tau_u[i] = fast_rcp(cAv[i] + cw + kap * cgrad + fixc);
-                tau_w[i] = fast_rcp((1.f + kap) * (cw + cgrad) + fixc);
-            } else {
-                tau_u[i] = fast_rcp(cAv[i] + cw + cgrad);
-                tau_w[i] = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const float cgrad = (float)((int)cl + (int)cr + (int)(r + i > 0) + (int)(r + i < g.Ny - 1));
+                const float cw = cWv[i] * g.inv_h;
+                if (MODEL == MODEL_IC) {
+                    tau_u[i] = fast_rcp(cAv[i] + cw + kap * cgrad + fixc);
+                    tau_w[i] = fast_rcp((1.f + kap) * (cw + cgrad) + fixc);
+                } else {
+                    tau_u[i] = fast_rcp(cAv[i] + cw + cgrad);
+                    tau_w[i] = 0.f;
+                }
             }
-        }
+        };
+        compute_tau();
         if (MODE == MODE_STEPS) {
             st4(ub, tau_u);
             if (MODEL == MODEL_IC) st4(wb, tau_w);
@@ -567,24 +572,20 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
             // low-res row of quad row i are fixed (x = r+i+3: phases 3,0,1,2; rows a,a+1,a+1,a+1 with
             // a = r/4), so the 4 x 3 low-res values sit in registers and the weights are scalars.
             const bool fast77 = MMC_FAST77 && PHASED && j33 && g.oy == -3 && g.ox == -3 && !(g.dbg & 2048);
-            float pv[4][3];
-            const float *wk = a.ckp;
-            if (fast77) {
+            const bool qborder = cborder || r == 0 || r + 4 >= g.Ny;      // the quad touches the frame border
+            if (g.dbg & 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ATp[i] = 0.f;
+            } else if (fast77 && !qborder) {
+                float pv[4][3];
                 const float *plb = pl + rq + g.PR * (Chi - Cbase);          // low-res rows a-2 .. a+1
 #pragma unroll
                 for (int jc = 0; jc < 3; ++jc)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) pv[k][jc] = plb[k - g.PR * jc];
-                wk = a.ckp + 12 * __builtin_amdgcn_readfirstlane(bc);
-            }
+                const float *wk = a.ckp + 12 * __builtin_amdgcn_readfirstlane(bc);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ri = r + i;
-                if (g.dbg & 4) {
-                    ATp[i] = 0.f;
-                } else if (cborder || ri == 0 || ri == g.Ny - 1) {
-                    ATp[i] = gather_ATp(g, a.cker, p, ri, c);
-                } else if (fast77) {
+                for (int i = 0; i < 4; ++i) {
                     const int br = (i + 3) & 3, dR = (i + 3) >> 2;
                     float s = 0.f;
 #pragma unroll
@@ -593,23 +594,40 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
                         for (int jr = 0; jr < 3; ++jr)
                             s += wk[br + 4 * jr + 48 * jc] * pv[dR - jr + 2][jc];
                     ATp[i] = s;
-                } else {
-                    const int x = ri - g.oy;
-                    const int Rhi = x / f, br = x - f * Rhi;
-                    const float *ck0 = ckp + br + g.MP * bc;
-                    const float *pl0 = pl + (Rhi - Rbase) + g.PR * (Chi - Cbase);
+                }
+            } else {
+                // Generic path.  The replicate border of the blur (helpers/RepConvMtx.m:23-32) folds
+                // every virtual row above the first / below the last row onto that row (same for
+                // columns), so a border pixel sums the interior formula over those virtual positions.
+                const int rvlast = max(g.f * (g.ny - 1) + g.oy + g.CH - 1, g.Ny - 1);
+                const int cvlast = max(g.f * (g.nx - 1) + g.ox + g.CW - 1, g.Nx - 1);
+                const int cv0 = c == 0 ? min(g.ox, 0) : c, cv1 = c == g.Nx - 1 ? cvlast : c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ri = r + i;
+                    const int rv0 = ri == 0 ? min(g.oy, 0) : ri, rv1 = ri == g.Ny - 1 ? rvlast : ri;
                     float s = 0.f;
-                    if (F == 4 && j33) {
-                        // 3 x 3 low-res taps (7x7 or 9x9 blur at zoom 4): MP = 12, fully unrolled
+                    for (int cv = cv0; cv <= cv1; ++cv) {
+                        const int xcv = cv - g.ox;
+                        const int Chv = xcv / f, bcv = xcv - f * Chv;
+                        for (int rv = rv0; rv <= rv1; ++rv) {
+                            const int x = rv - g.oy;
+                            const int Rhi = x / f, br = x - f * Rhi;
+                            const float *ck0 = ckp + br + g.MP * bcv;
+                            const float *pl0 = pl + (Rhi - Rbase) + g.PR * (Chv - Cbase);
+                            if (F == 4 && j33) {
+                                // 3 x 3 low-res taps (7x7 or 9x9 blur at zoom 4): MP = 12, fully unrolled
 #pragma unroll
-                        for (int jc = 0; jc < 3; ++jc)
+                                for (int jc = 0; jc < 3; ++jc)
 #pragma unroll
-                            for (int jr = 0; jr < 3; ++jr)
-                                s += ck0[4 * jr + 48 * jc] * pl0[-jr - g.PR * jc];
-                    } else {
-                        for (int jc = 0; jc < g.Jc; ++jc)
-                            for (int jr = 0; jr < g.Jr; ++jr)
-                                s += ck0[f * jr + g.MP * f * jc] * pl0[-jr - g.PR * jc];
+                                    for (int jr = 0; jr < 3; ++jr)
+                                        s += ck0[4 * jr + 48 * jc] * pl0[-jr - g.PR * jc];
+                            } else {
+                                for (int jc = 0; jc < g.Jc; ++jc)
+                                    for (int jr = 0; jr < g.Jr; ++jr)
+                                        s += ck0[f * jr + g.MP * f * jc] * pl0[-jr - g.PR * jc];
+                            }
+                        }
                     }
                     ATp[i] = s;
                 }
