@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MMC_ABI_VERSION 1
+#define MMC_ABI_VERSION 2
 
 typedef enum mmc_status {
     MMC_OK = 0,
@@ -51,7 +51,8 @@ typedef enum mmc_flow_direction {
 /* interpMethod, MultiframeMotionCoupling.m:237-239, helpers/samplingOperator.m */
 typedef enum mmc_sampling {
     MMC_SAMPLING_AVERAGE = 0,   /* 'average': block mean; exact only for factor 4 */
-    MMC_SAMPLING_STRIDE = 1     /* 'stride' : every factor-th pixel from top-left */
+    MMC_SAMPLING_STRIDE = 1,    /* 'stride' : every factor-th pixel from top-left */
+    MMC_SAMPLING_TAPS = 2       /* any separable sampler, given by mmc_set_sampling_taps */
 } mmc_sampling;
 
 /* Versioned POD.  Set size = sizeof(mmc_params), version = MMC_ABI_VERSION. */
@@ -130,6 +131,18 @@ int mmc_set_lowres(mmc_handle *h, const float *f);
  * means no blur (MultiframeMotionCoupling.m:373).  Replaces RepConvMtx and its
  * composition with samplingOperator, MultiframeMotionCoupling.m:368-375. */
 int mmc_set_blur(mmc_handle *h, const float *k, int kh, int kw);
+
+/* The separable sampling operator S = kron(Sx', Sy) of helpers/samplingOperator.m:77-83 for the
+ * interpMethods other than 'average'/'stride' ('nearest', 'bilinear', 'bicubic', 'lanczos2',
+ * 'lanczos3', 'custom', with or without antialiasing, :99-136), handed over as its two 1-D
+ * factors (Dim1Matrix, :89-146) in banded form: low-res row R takes taps_y weights
+ * w_y[R*taps_y ...] from the high-res rows first_y[R], first_y[R]+1, ... (0-based; a position
+ * outside the frame must carry weight 0); likewise for columns.  Rows away from the border must
+ * be shifted copies of one another (they are for an integer zoom factor); the rows near the
+ * border, where imresize folds the taps beyond the edge onto the edge pixel, may differ and are
+ * applied exactly.  Needs params.sampling == MMC_SAMPLING_TAPS; call before mmc_init. */
+int mmc_set_sampling_taps(mmc_handle *h, const int32_t *first_y, const float *w_y, int taps_y,
+                          const int32_t *first_x, const float *w_x, int taps_x);
 
 /* Flow fields of the pairs this block touches: global pairs
  * [max(frame_begin-1,0), min(frame_end, nc_global-1)), laid out

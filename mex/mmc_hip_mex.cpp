@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -110,6 +111,38 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         if (mxIsEmpty(prhs[2])) { check(mmc_set_blur(e.h, nullptr, 0, 0), e.h); return; }
         std::vector<float> k = to_float(prhs[2]);
         check(mmc_set_blur(e.h, k.data(), (int)mxGetM(prhs[2]), (int)mxGetN(prhs[2])), e.h);
+    } else if (cmd == "sampling") {
+        // mmc_hip_mex('sampling', handle, Sy, Sx): the two 1-D factors of samplingOperator
+        // (full or sparse doubles, ny x Ny and nx x Nx); rows are handed over in banded form.
+        Entry &e = lookup(prhs[1]);
+        std::vector<int32_t> first[2];
+        std::vector<float> w[2];
+        int T[2] = {0, 0};
+        for (int ax = 0; ax < 2; ++ax) {
+            mxArray *full = nullptr;
+            const mxArray *S = prhs[2 + ax];
+            if (mxIsSparse(S)) {
+                mxArray *in = const_cast<mxArray *>(S);
+                mexCallMATLAB(1, &full, 1, &in, "full");
+                S = full;
+            }
+            const size_t nout = mxGetM(S), nin = mxGetN(S);
+            const double *d = mxGetDoubles(S);
+            std::vector<int> lo(nout, (int)nin), hi(nout, -1);
+            for (size_t c = 0; c < nin; ++c)
+                for (size_t r = 0; r < nout; ++r)
+                    if (d[r + nout * c] != 0.0) { lo[r] = std::min(lo[r], (int)c); hi[r] = std::max(hi[r], (int)c); }
+            for (size_t r = 0; r < nout; ++r) if (hi[r] >= lo[r]) T[ax] = std::max(T[ax], hi[r] - lo[r] + 1);
+            if (T[ax] == 0) mexErrMsgIdAndTxt("MMC:hip", "empty sampling matrix");
+            first[ax].resize(nout);
+            w[ax].assign(nout * (size_t)T[ax], 0.f);
+            for (size_t r = 0; r < nout; ++r) {
+                first[ax][r] = std::max(std::min(lo[r], (int)nin - T[ax]), 0);
+                for (int m = 0; m < T[ax]; ++m) w[ax][r * T[ax] + m] = (float)d[r + nout * (size_t)(first[ax][r] + m)];
+            }
+            if (full) mxDestroyArray(full);
+        }
+        check(mmc_set_sampling_taps(e.h, first[0].data(), w[0].data(), T[0], first[1].data(), w[1].data(), T[1]), e.h);
     } else if (cmd == "flow") {
         Entry &e = lookup(prhs[1]);
         std::vector<float> v = to_float(prhs[2]);

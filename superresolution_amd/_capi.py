@@ -12,11 +12,11 @@ import numpy as np
 
 from .build import LIB_PATH
 
-MMC_ABI_VERSION = 1
+MMC_ABI_VERSION = 2
 MMC_NUM_SUMS = 4
 
 FLOW_FORWARD, FLOW_BACKWARD, FLOW_FORWARD_BACKWARD = 0, 1, 2
-SAMPLING_AVERAGE, SAMPLING_STRIDE = 0, 1
+SAMPLING_AVERAGE, SAMPLING_STRIDE, SAMPLING_TAPS = 0, 1, 2
 
 STATUS_NAMES = {0: "MMC_OK", -1: "MMC_ERR_INVALID_ARG", -2: "MMC_ERR_STATE", -3: "MMC_ERR_HIP",
                 -4: "MMC_ERR_UNSUPPORTED", -5: "MMC_ERR_NO_DEVICE"}
@@ -65,6 +65,7 @@ SIGNATURES = {
     "mmc_set_lowres": (C.c_int, [_H, _fp]),
     "mmc_set_blur": (C.c_int, [_H, _fp, C.c_int, C.c_int]),
     "mmc_set_flow": (C.c_int, [_H, _fp, _u8p]),
+    "mmc_set_sampling_taps": (C.c_int, [_H, C.POINTER(C.c_int32), _fp, C.c_int, C.POINTER(C.c_int32), _fp, C.c_int]),
     "mmc_num_flow_pairs": (C.c_int, [_H]),
     "mmc_set_state": (C.c_int, [_H, _fp, _fp]),
     "mmc_num_state_frames": (C.c_int, [_H]),

@@ -25,6 +25,12 @@ struct mmc_handle {
     int pair_lo = 0, npairs = 0;          // global pairs [pair_lo, pair_lo+npairs) this block touches
     std::vector<float> blur;              // kh x kw column-major; empty = no blur
     int kh = 1, kw = 1;
+    // 1-D factors of the sampling operator in banded form (mmc_set_sampling_taps); empty: 'average' / 'stride'
+    std::vector<int> sfy, sfx;
+    std::vector<double> swy, swx;
+    int sty = 0, stx = 0;
+    bool dataop_built = false;            // composite kernel, step sizes and border correction are current
+    std::vector<void *> eallocs;          // device buffers of the border correction
     bool have_f = false, have_flow = false, have_state = false, inited = false, have_h = false;
     float h = 1.f;
     std::vector<void *> allocs;
@@ -92,11 +98,12 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
         return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: frame block must be a non-empty range inside [0, nc_global)");
     if (p->flow_direction < 0 || p->flow_direction > 2)
         return fail(nullptr, MMC_ERR_INVALID_ARG, "Invalid flow direction.");
-    if (p->sampling != MMC_SAMPLING_AVERAGE && p->sampling != MMC_SAMPLING_STRIDE)
-        return fail(nullptr, MMC_ERR_UNSUPPORTED, "interpMethod: only 'average' and 'stride' are implemented");
+    if (p->sampling != MMC_SAMPLING_AVERAGE && p->sampling != MMC_SAMPLING_STRIDE && p->sampling != MMC_SAMPLING_TAPS)
+        return fail(nullptr, MMC_ERR_UNSUPPORTED, "interpMethod: unknown sampling code");
     if (p->sampling == MMC_SAMPLING_AVERAGE && p->factor != 4)
         return fail(nullptr, MMC_ERR_UNSUPPORTED,
-                    "interpMethod 'average' is a block mean only for factor 4 (samplingOperator.m:70-73); other factors are not implemented");
+                    "interpMethod 'average' is a block mean only for factor 4 (samplingOperator.m:70-73); for other factors pass "
+                    "the rows of the sampling matrix with mmc_set_sampling_taps");
     if ((long long)p->ny * p->factor * (long long)p->nx * p->factor > (long long)INT_MAX / 4)
         return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: frame too large for 32-bit pixel indexing");
 
@@ -188,6 +195,7 @@ extern "C" int mmc_destroy(mmc_handle *h) {
     hipSetDevice(h->prm.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
+    for (void *p : h->eallocs) hipFree(p);
     for (hipEvent_t e : h->events) hipEventDestroy(e);
     for (hipEvent_t e : h->sweep_events) hipEventDestroy(e);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -212,16 +220,43 @@ extern "C" int mmc_set_lowres(mmc_handle *h, const float *f) {
 
 extern "C" int mmc_set_blur(mmc_handle *h, const float *k, int kh, int kw) {
     REQUIRE_HANDLE(h);
-    if (!k) { h->blur.clear(); h->kh = h->kw = 1; h->inited = false; return MMC_OK; }
+    if (!k) { h->blur.clear(); h->kh = h->kw = 1; h->inited = false; h->dataop_built = false; return MMC_OK; }
     // helpers/RepConvMtx.m:6-8
     if (kh <= 0 || kw <= 0 || (kh % 2) != 1 || (kw % 2) != 1)
         return fail(h, MMC_ERR_INVALID_ARG, "kernel has even dimensions (which is not implemented)");
-    const int td = h->prm.sampling == MMC_SAMPLING_AVERAGE ? h->prm.factor : 1;
-    if (kh + td - 1 > MMC_MAX_CK || kw + td - 1 > MMC_MAX_CK)
+    if (kh > MMC_MAX_CK || kw > MMC_MAX_CK)
         return fail(h, MMC_ERR_UNSUPPORTED, "mmc_set_blur: blur kernel too large");
     h->blur.assign(k, k + (size_t)kh * kw);
     h->kh = kh; h->kw = kw;
     h->inited = false;
+    h->dataop_built = false;
+    return MMC_OK;
+}
+
+extern "C" int mmc_set_sampling_taps(mmc_handle *h, const int32_t *first_y, const float *w_y, int taps_y,
+                                     const int32_t *first_x, const float *w_x, int taps_x) {
+    REQUIRE_HANDLE(h);
+    if (h->prm.sampling != MMC_SAMPLING_TAPS)
+        return fail(h, MMC_ERR_STATE, "mmc_set_sampling_taps: the handle was not created with MMC_SAMPLING_TAPS");
+    if (!first_y || !w_y || !first_x || !w_x || taps_y <= 0 || taps_x <= 0)
+        return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_sampling_taps: null or empty taps");
+    const Geom &g = h->g;
+    for (int ax = 0; ax < 2; ++ax) {
+        const int nout = ax ? g.nx : g.ny, nin = ax ? g.Nx : g.Ny, T = ax ? taps_x : taps_y;
+        const int32_t *first = ax ? first_x : first_y;
+        const float *w = ax ? w_x : w_y;
+        for (int R = 0; R < nout; ++R)
+            for (int m = 0; m < T; ++m) {
+                const float v = w[(size_t)R * T + m];
+                if (!std::isfinite(v)) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_sampling_taps: weight is not finite");
+                if (v != 0.f && (first[R] + m < 0 || first[R] + m >= nin))
+                    return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_sampling_taps: non-zero weight outside the frame");
+            }
+    }
+    h->sfy.assign(first_y, first_y + g.ny); h->swy.assign(w_y, w_y + (size_t)g.ny * taps_y); h->sty = taps_y;
+    h->sfx.assign(first_x, first_x + g.nx); h->swx.assign(w_x, w_x + (size_t)g.nx * taps_x); h->stx = taps_x;
+    h->inited = false;
+    h->dataop_built = false;
     return MMC_OK;
 }
 
@@ -301,26 +336,116 @@ extern "C" int mmc_set_fixed_frame(mmc_handle *h, const float *u0, const float *
     return MMC_OK;
 }
 
-// Composite kernel of (sampling taps) * (flipped blur), and the abs row / column
-// sums of A = D*B with the replicate border of RepConvMtx.m:23-32 merged.
+// One axis of the sampling operator: the interior row shape (taps d, first tap at f*R + od for
+// low-res index R) and the rows that deviate from it (near the border, where imresize folds the
+// taps beyond the edge onto the edge pixel, helpers/samplingOperator.m:118-121).
+struct AxisOp {
+    std::vector<int> first;       // banded rows as given
+    std::vector<double> w;
+    int T = 0;
+    std::vector<double> d;        // interior taps
+    int od = 0;
+    std::vector<char> special;    // row is not the shifted interior row
+};
+
+static int analyse_axis(mmc_handle *h, AxisOp &ax, int f, int nout, int nin) {
+    const int Rm = nout / 2, T = ax.T;
+    int lo = 0, hi = T - 1;
+    while (lo < T && ax.w[(size_t)Rm * T + lo] == 0.0) ++lo;
+    while (hi >= 0 && ax.w[(size_t)Rm * T + hi] == 0.0) --hi;
+    if (hi < lo) return fail(h, MMC_ERR_INVALID_ARG, "sampling taps: the middle row is empty");
+    ax.d.assign(ax.w.begin() + (size_t)Rm * T + lo, ax.w.begin() + (size_t)Rm * T + hi + 1);
+    ax.od = ax.first[Rm] + lo - f * Rm;
+    double dmax = 0.0;
+    for (double v : ax.d) dmax = std::max(dmax, std::fabs(v));
+    const double tol = 1e-6 * dmax;
+    const int nd = (int)ax.d.size();
+    ax.special.assign((size_t)nout, 0);
+    int nspecial = 0;
+    for (int R = 0; R < nout; ++R) {
+        const int base = f * R + ax.od;
+        bool same = base >= 0 && base + nd <= nin;
+        for (int m = 0; same && m < T; ++m) {                 // every given weight is the interior one
+            const int k = ax.first[R] + m - base;
+            const double want = (k >= 0 && k < nd) ? ax.d[k] : 0.0;
+            same = std::fabs(ax.w[(size_t)R * T + m] - want) <= tol;
+        }
+        for (int k = 0; same && k < nd; ++k) {                // and every interior tap is given
+            const int m = base + k - ax.first[R];
+            if (ax.d[k] != 0.0 && (m < 0 || m >= T)) same = false;
+        }
+        ax.special[R] = !same;
+        nspecial += !same;
+    }
+    if (2 * nspecial > nout && nout > 64)      // every such row becomes an explicit sparse row
+        return fail(h, MMC_ERR_UNSUPPORTED, "sampling taps: rows are not shifted copies of one another (non-integer zoom?)");
+    return MMC_OK;
+}
+
+static void free_correction(mmc_handle *h) {
+    for (void *p : h->eallocs) hipFree(p);
+    h->eallocs.clear();
+    Arrays &a = h->a;
+    a.ne = a.net = 0;
+    a.e_row = a.e_ptr = a.e_col = a.et_row = a.et_ptr = a.et_col = nullptr;
+    a.e_val = a.et_val = a.pcorr = a.ucorr = nullptr;
+}
+
+template <typename T>
+static int upload_vec(mmc_handle *h, T **dst, const std::vector<T> &v) {
+    void *p = nullptr;
+    HIPCHK(h, hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    h->eallocs.push_back(p);
+    HIPCHK(h, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    *dst = (T *)p;
+    return MMC_OK;
+}
+
+// A = S*B per frame (MultiframeMotionCoupling.m:368-375): composite kernel of (interior sampling
+// taps) x (flipped blur) for the kernels, exact abs row / column sums of A for the step sizes with
+// the replicate border of RepConvMtx.m:23-32 merged, and, for the low-res pixels whose sampling
+// rows deviate from the interior shape, the sparse difference between the exact row of A and the
+// composite kernel applied with a single clamp.
 static int build_data_operator(mmc_handle *h) {
+    if (h->dataop_built) return MMC_OK;
     Geom &g = h->g;
-    const int td = h->prm.sampling == MMC_SAMPLING_AVERAGE ? g.f : 1;
-    const double wd = 1.0 / td;
-    const int kh = h->kh, kw = h->kw;
-    g.CH = td + kh - 1; g.CW = td + kw - 1;
-    g.oy = -(kh / 2); g.ox = -(kw / 2);
-    if (g.f * (g.ny - 1) + td - 1 > g.Ny - 1 || g.f * (g.nx - 1) + td - 1 > g.Nx - 1)
-        return fail(h, MMC_ERR_UNSUPPORTED, "sampling window leaves the image");
+    const int kh = h->kh, kw = h->kw, f = g.f;
+    AxisOp ay, ax;
+    if (h->prm.sampling == MMC_SAMPLING_TAPS) {
+        if (h->sty <= 0) return fail(h, MMC_ERR_STATE, "mmc_init: no sampling taps (mmc_set_sampling_taps)");
+        ay.first = h->sfy; ay.w = h->swy; ay.T = h->sty;
+        ax.first = h->sfx; ax.w = h->swx; ax.T = h->stx;
+    } else {
+        // 'average' at factor 4 = rows [1/4 1/4 1/4 1/4] (samplingOperator.m:70-73); 'stride' = one tap (:137-141)
+        const int td = h->prm.sampling == MMC_SAMPLING_AVERAGE ? f : 1;
+        for (int axn = 0; axn < 2; ++axn) {
+            AxisOp &o = axn ? ax : ay;
+            const int nout = axn ? g.nx : g.ny;
+            o.T = td;
+            o.first.resize((size_t)nout);
+            o.w.assign((size_t)nout * td, 1.0 / td);
+            for (int R = 0; R < nout; ++R) o.first[R] = f * R;
+        }
+    }
+    int rc;
+    if ((rc = analyse_axis(h, ay, f, g.ny, g.Ny))) return rc;
+    if ((rc = analyse_axis(h, ax, f, g.nx, g.Nx))) return rc;
+    const int tdy = (int)ay.d.size(), tdx = (int)ax.d.size();
+    // composite kernel; a first tap below / right of f*R is moved back onto it with zero rows
+    const int py = std::max(ay.od - kh / 2, 0), px = std::max(ax.od - kw / 2, 0);
+    g.CH = tdy + kh - 1 + py; g.CW = tdx + kw - 1 + px;
+    g.oy = ay.od - kh / 2 - py; g.ox = ax.od - kw / 2 - px;
+    if (g.CH > MMC_MAX_CK || g.CW > MMC_MAX_CK)
+        return fail(h, MMC_ERR_UNSUPPORTED, "sampling taps x blur kernel too large");
+    auto kflip = [&](int i, int j) {      // flipped kernel: true convolution, RepConvMtx.m:33
+        return h->blur.empty() ? 1.0 : (double)h->blur[(size_t)(kh - 1 - i) + (size_t)kh * (kw - 1 - j)];
+    };
     std::vector<double> ck((size_t)g.CH * g.CW, 0.0);
-    for (int b = 0; b < td; ++b)
-        for (int aa = 0; aa < td; ++aa)
+    for (int b = 0; b < tdx; ++b)
+        for (int aa = 0; aa < tdy; ++aa)
             for (int j = 0; j < kw; ++j)
-                for (int i = 0; i < kh; ++i) {
-                    // flipped kernel: true convolution, RepConvMtx.m:33
-                    double kv = h->blur.empty() ? 1.0 : (double)h->blur[(size_t)(kh - 1 - i) + (size_t)kh * (kw - 1 - j)];
-                    ck[(size_t)(aa + i) + (size_t)g.CH * (b + j)] += wd * wd * kv;
-                }
+                for (int i = 0; i < kh; ++i)
+                    ck[(size_t)(py + aa + i) + (size_t)g.CH * (px + b + j)] += ay.d[aa] * ax.d[b] * kflip(i, j);
     std::vector<float> ckf(ck.begin(), ck.end());
     g.Jr = (g.CH + g.f - 1) / g.f; g.Jc = (g.CW + g.f - 1) / g.f;
     g.MP = g.f * g.Jr; g.NP = g.f * g.Jc;
@@ -345,31 +470,36 @@ static int build_data_operator(mmc_handle *h) {
         for (int mm = 0; mm < g.CH; ++mm) ckq[(size_t)(g.wpad + mm) + (size_t)g.MPq * nn] = ckf[(size_t)mm + (size_t)g.CH * nn];
     HIPCHK(h, hipMemcpyAsync(h->a.ckq, ckq.data(), ckq.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+
+    auto clampi = [](int v, int hi) { return std::min(std::max(v, 0), hi); };
     std::vector<double> colsum((size_t)g.N, 0.0);
     std::vector<float> sig((size_t)g.n);
     std::vector<double> merged((size_t)g.CH * g.CW);
+    // correction rows: (low-res pixel, [(high-res pixel, value)])
+    std::vector<int> e_row, e_ptr(1, 0), e_col;
+    std::vector<float> e_val;
+    std::vector<double> patch;
     for (int C = 0; C < g.nx; ++C)
         for (int R = 0; R < g.ny; ++R) {
-            // merge taps that clamp onto the same pixel before taking |.|
             const int rbase = g.f * R + g.oy, cbase = g.f * C + g.ox;
+            const bool special = ay.special[R] || ax.special[C];
             const bool border = rbase < 0 || cbase < 0 || rbase + g.CH > g.Ny || cbase + g.CW > g.Nx;
             double rowsum = 0.0;
-            if (!border) {
+            if (!special && !border) {
                 for (int nn = 0; nn < g.CW; ++nn)
                     for (int mm = 0; mm < g.CH; ++mm) {
                         const double v = std::fabs((double)ckf[(size_t)mm + (size_t)g.CH * nn]);
                         rowsum += v;
                         colsum[(size_t)(rbase + mm) + (size_t)g.Ny * (cbase + nn)] += v;
                     }
-            } else {
+            } else if (!special) {
+                // interior sampling row, blur clamps at the frame border: merge taps that land on one pixel
                 std::fill(merged.begin(), merged.end(), 0.0);
-                const int rlo = std::min(std::max(rbase, 0), g.Ny - 1), clo = std::min(std::max(cbase, 0), g.Nx - 1);
+                const int rlo = clampi(rbase, g.Ny - 1), clo = clampi(cbase, g.Nx - 1);
                 for (int nn = 0; nn < g.CW; ++nn)
-                    for (int mm = 0; mm < g.CH; ++mm) {
-                        const int rr = std::min(std::max(rbase + mm, 0), g.Ny - 1);
-                        const int cc = std::min(std::max(cbase + nn, 0), g.Nx - 1);
-                        merged[(size_t)(rr - rlo) + (size_t)g.CH * (cc - clo)] += (double)ckf[(size_t)mm + (size_t)g.CH * nn];
-                    }
+                    for (int mm = 0; mm < g.CH; ++mm)
+                        merged[(size_t)(clampi(rbase + mm, g.Ny - 1) - rlo) + (size_t)g.CH * (clampi(cbase + nn, g.Nx - 1) - clo)] +=
+                            (double)ckf[(size_t)mm + (size_t)g.CH * nn];
                 for (int nn = 0; nn < g.CW; ++nn)
                     for (int mm = 0; mm < g.CH; ++mm) {
                         const double v = std::fabs(merged[(size_t)mm + (size_t)g.CH * nn]);
@@ -377,6 +507,42 @@ static int build_data_operator(mmc_handle *h) {
                         rowsum += v;
                         colsum[(size_t)(rlo + mm) + (size_t)g.Ny * (clo + nn)] += v;
                     }
+            } else {
+                // exact row of S*B for this pixel, and what the kernels compute for it
+                const int fy0 = ay.first[R], fx0 = ax.first[C];
+                const int r_lo = std::min(clampi(fy0 - kh / 2, g.Ny - 1), clampi(rbase, g.Ny - 1));
+                const int r_hi = std::max(clampi(fy0 + ay.T - 1 + kh / 2, g.Ny - 1), clampi(rbase + g.CH - 1, g.Ny - 1));
+                const int c_lo = std::min(clampi(fx0 - kw / 2, g.Nx - 1), clampi(cbase, g.Nx - 1));
+                const int c_hi = std::max(clampi(fx0 + ax.T - 1 + kw / 2, g.Nx - 1), clampi(cbase + g.CW - 1, g.Nx - 1));
+                const int PH = r_hi - r_lo + 1, PW = c_hi - c_lo + 1;
+                patch.assign((size_t)2 * PH * PW, 0.0);          // [0]: exact, [1]: composite
+                double *ex = patch.data(), *co = patch.data() + (size_t)PH * PW;
+                for (int b = 0; b < ax.T; ++b) {
+                    const double wx = ax.w[(size_t)C * ax.T + b];
+                    if (wx == 0.0) continue;
+                    for (int aa = 0; aa < ay.T; ++aa) {
+                        const double wy = ay.w[(size_t)R * ay.T + aa];
+                        if (wy == 0.0) continue;
+                        for (int j = 0; j < kw; ++j)
+                            for (int i = 0; i < kh; ++i) {
+                                const int rr = clampi(fy0 + aa + i - kh / 2, g.Ny - 1), cc = clampi(fx0 + b + j - kw / 2, g.Nx - 1);
+                                ex[(size_t)(rr - r_lo) + (size_t)PH * (cc - c_lo)] += wy * wx * kflip(i, j);
+                            }
+                    }
+                }
+                for (int nn = 0; nn < g.CW; ++nn)
+                    for (int mm = 0; mm < g.CH; ++mm)
+                        co[(size_t)(clampi(rbase + mm, g.Ny - 1) - r_lo) + (size_t)PH * (clampi(cbase + nn, g.Nx - 1) - c_lo)] +=
+                            (double)ckf[(size_t)mm + (size_t)g.CH * nn];
+                for (int cc = 0; cc < PW; ++cc)
+                    for (int rr = 0; rr < PH; ++rr) {
+                        const double v = ex[(size_t)rr + (size_t)PH * cc];
+                        const double e = v - co[(size_t)rr + (size_t)PH * cc];
+                        const size_t hr = (size_t)(r_lo + rr) + (size_t)g.Ny * (c_lo + cc);
+                        if (v != 0.0) { rowsum += std::fabs(v); colsum[hr] += std::fabs(v); }
+                        if (std::fabs(e) > 1e-9) { e_col.push_back((int)hr); e_val.push_back((float)e); }
+                    }
+                if ((int)e_col.size() > e_ptr.back()) { e_row.push_back(R + g.ny * C); e_ptr.push_back((int)e_col.size()); }
             }
             sig[(size_t)R + (size_t)g.ny * C] = rowsum > 0.0 ? (float)(1.0 / rowsum) : 1.f;
         }
@@ -385,6 +551,45 @@ static int build_data_operator(mmc_handle *h) {
     HIPCHK(h, hipMemcpyAsync(h->a.cA, colf.data(), colf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->a.sigp, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+
+    free_correction(h);
+    if (!e_row.empty()) {
+        // transpose: rows = high-res pixels
+        std::vector<int> hr_ids(e_col);
+        std::sort(hr_ids.begin(), hr_ids.end());
+        hr_ids.erase(std::unique(hr_ids.begin(), hr_ids.end()), hr_ids.end());
+        std::vector<int> et_ptr(hr_ids.size() + 1, 0), et_col(e_col.size());
+        std::vector<float> et_val(e_col.size());
+        auto slot = [&](int hr) { return (int)(std::lower_bound(hr_ids.begin(), hr_ids.end(), hr) - hr_ids.begin()); };
+        for (int c : e_col) et_ptr[(size_t)slot(c) + 1]++;
+        for (size_t i = 1; i < et_ptr.size(); ++i) et_ptr[i] += et_ptr[i - 1];
+        std::vector<int> fill(et_ptr.begin(), et_ptr.end() - 1);
+        for (size_t r = 0; r < e_row.size(); ++r)
+            for (int k = e_ptr[r]; k < e_ptr[r + 1]; ++k) {
+                const int dst = fill[(size_t)slot(e_col[k])]++;
+                et_col[dst] = e_row[r];
+                et_val[dst] = e_val[k];
+            }
+        Arrays &a = h->a;
+        if ((rc = upload_vec(h, &a.e_row, e_row)) || (rc = upload_vec(h, &a.e_ptr, e_ptr)) ||
+            (rc = upload_vec(h, &a.e_col, e_col)) || (rc = upload_vec(h, &a.e_val, e_val)) ||
+            (rc = upload_vec(h, &a.et_row, hr_ids)) || (rc = upload_vec(h, &a.et_ptr, et_ptr)) ||
+            (rc = upload_vec(h, &a.et_col, et_col)) || (rc = upload_vec(h, &a.et_val, et_val)))
+            return rc;
+        a.ne = (int)e_row.size();
+        a.net = (int)hr_ids.size();
+        void *pc = nullptr, *uc = nullptr;
+        HIPCHK(h, hipMalloc(&pc, (size_t)h->L * g.n * sizeof(float)));
+        h->eallocs.push_back(pc);
+        HIPCHK(h, hipMalloc(&uc, (size_t)h->L * g.N * sizeof(float)));
+        h->eallocs.push_back(uc);
+        HIPCHK(h, hipMemsetAsync(pc, 0, (size_t)h->L * g.n * sizeof(float), h->stream));
+        HIPCHK(h, hipMemsetAsync(uc, 0, (size_t)h->L * g.N * sizeof(float), h->stream));
+        a.pcorr = (float *)pc;
+        a.ucorr = (float *)uc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->dataop_built = true;
     return MMC_OK;
 }
 

@@ -22,7 +22,7 @@ enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3 };
 #endif
 enum { TILE_R = MMC_TILE_R, TILE_C = MMC_TILE_C, MMC_THREADS = MMC_NTHREADS };
 static_assert(TILE_R * TILE_C == 4 * MMC_THREADS && (TILE_R & (TILE_R - 1)) == 0, "tile must hold one row quad per thread");
-enum { MMC_MAX_CK = 24 };      // max side of the composite (sampling * blur) kernel
+enum { MMC_MAX_CK = 40 };      // max side of the composite (sampling * blur) kernel
 enum { MMC_WARP_MAX = 2304 }; // floats of the warped frame a tile may stage in LDS per plane
 enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
 enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device
@@ -82,6 +82,13 @@ struct Arrays {
     float *cker;               // composite kernel, CH x CW column-major
     float *ckp;                // the same, zero-padded to MP x NP
     float *ckq;                // the same, wpad zero rows on top, zero-padded to MPq x CW
+    // Sparse correction E = A - (composite kernel with one replicate clamp), non-zero only on the low-res
+    // pixels whose sampling rows are not the interior ones; all null when the sampler has none.
+    int ne, net;               // rows of E (low-res pixels) and of E' (high-res pixels)
+    int *e_row, *e_ptr, *e_col;   float *e_val;
+    int *et_row, *et_ptr, *et_col; float *et_val;
+    float *pcorr;              // E xbar_u, L*n (zero off the rows of E)
+    float *ucorr;              // E' p, L*N (zero off the rows of E')
     int *bbox;                 // [(L+1) pair slots][ntiles][4] = rmin,rmax,cmin,cmax of the SOURCES of a tile
     int *tbox;                 // [L pair slots][ntiles][4] = rows/cols of the warped frame a tile's TAPS touch
     double *sums;              // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]

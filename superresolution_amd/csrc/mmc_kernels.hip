@@ -317,6 +317,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
         const float div1 = grad_adj(g, g1x, g1y, r, c, j);
         const float ATp = gather_ATp(g, a.cker, p, r, c);
         float KTu = ATp + g.inv_h * Wt1 + kap * div1;
+        if (a.ucorr) KTu += a.ucorr[(size_t)t * g.N + j];      // rows of A that deviate from the composite kernel
         float KTw = 0.f;
         if (MODEL == MODEL_IC) {
             const float div2 = grad_adj(g, g2x, g2y, r, c, j);
@@ -633,6 +634,12 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
                 }
             }
             float KTu[4], KTw[4];
+            if (a.ucorr) {      // rows of A that deviate from the composite kernel
+                float uc[4];
+                ld4(uc, a.ucorr + (size_t)t * g.N + j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ATp[i] += uc[i];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 KTu[i] = ATp[i] + g.inv_h * Wt1[i] + kap * div1[i];
@@ -848,6 +855,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0
         }
         const size_t o = (size_t)t * g.n + i;
         const float sg = a.sigp[i];
+        if (a.pcorr) acc += a.pcorr[o];
         if (MODE == MODE_RAW) {
             a.p[o] = acc;
         } else if (MODE == MODE_STEPS) {
@@ -1161,6 +1169,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < MMC_THREADS / 64; ++k) acc += psum[k * nlr + lp];
+        if (a.pcorr) acc += a.pcorr[o];
         if (MODE == MODE_RAW) {
             a.p[o] = acc;
         } else if (MODE == MODE_ENERGY) {
@@ -1174,6 +1183,30 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     }
     if (MODE == MODE_ENERGY) { float e[2] = {part[0], epart}; block_accumulate<2>(e, a.sums, 4); }
     else if (REDUCE) block_accumulate<2>(part, a.sums, 2);
+}
+
+// --------------------------------------------------------------------------
+// sparse border correction of the data operator (samplers whose rows near the
+// frame border deviate from the interior taps): pcorr = E xbar_u, ucorr = E' p
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(MMC_THREADS) void k_corr_p(Geom g, Arrays a, int t0, int nf) {
+    const int idx = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (idx >= a.ne * nf) return;
+    const int tr = idx / a.ne, e = idx - tr * a.ne, t = t0 + tr;
+    const float *ub = FR(a.ub, t);
+    float s = 0.f;
+    for (int k = a.e_ptr[e]; k < a.e_ptr[e + 1]; ++k) s += a.e_val[k] * ub[a.e_col[k]];
+    a.pcorr[(size_t)t * g.n + a.e_row[e]] = s;
+}
+
+__global__ __launch_bounds__(MMC_THREADS) void k_corr_u(Geom g, Arrays a, int t0, int nf) {
+    const int idx = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (idx >= a.net * nf) return;
+    const int tr = idx / a.net, e = idx - tr * a.net, t = t0 + tr;
+    const float *p = a.p + (size_t)t * g.n;
+    float s = 0.f;
+    for (int k = a.et_ptr[e]; k < a.et_ptr[e + 1]; ++k) s += a.et_val[k] * p[a.et_col[k]];
+    a.ucorr[(size_t)t * g.N + a.et_row[e]] = s;
 }
 
 // --------------------------------------------------------------------------
@@ -1318,6 +1351,10 @@ static void launch_primal4(const Geom &g, const Arrays &a, int t0, int nf, int m
 
 hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s) {
     if (t1 <= t0) return hipSuccess;
+    if (a.net > 0 && mode != MODE_STEPS) {
+        const int total = a.net * (t1 - t0);
+        hipLaunchKernelGGL(k_corr_u, dim3((total + MMC_THREADS - 1) / MMC_THREADS), dim3(MMC_THREADS), 0, s, g, a, t0, t1 - t0);
+    }
     if (g.Ny % 4 == 0) {   // row-quad kernels need 16-byte aligned columns
         if (g.f == 4) launch_primal4<4>(g, a, t0, t1 - t0, mode, reduce, s);
         else launch_primal4<0>(g, a, t0, t1 - t0, mode, reduce, s);
@@ -1364,6 +1401,10 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
                            hipEvent_t mid) {
     if (t1 <= t0) return hipSuccess;
     const int nf = t1 - t0;
+    if (a.ne > 0 && mode != MODE_STEPS) {
+        const int total = a.ne * nf;
+        hipLaunchKernelGGL(k_corr_p, dim3((total + MMC_THREADS - 1) / MMC_THREADS), dim3(MMC_THREADS), 0, s, g, a, t0, nf);
+    }
     if (g.Ny % 4 == 0 && TILE_R % g.f == 0 && TILE_C % g.f == 0 && !(g.dbg & 16)) {
         // fused row-quad kernel: regulariser duals and data-term dual in one launch
         if (g.f == 4) launch_dual4<4>(g, a, t0, nf, mode, reduce, s);

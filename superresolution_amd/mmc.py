@@ -171,8 +171,22 @@ class MultiframeMotionCoupling(object):
             raise ValueError("flowField must be %s, got %s" % ((Ny, Nx, nc - 1, 2), v.shape))
         if self._solver is not None:
             self._solver.close()
+        # 'average' at zoom 4 and 'stride' are built into the library; every other sampler of
+        # samplingOperator.m (:368-370) is handed over as the rows of its two 1-D factors
+        builtin = self.interpMethod == "stride" or (self.interpMethod == "average" and int(self.factor) == 4
+                                                    and not self.interpAA)
         s = FrameBlockSolver(ny, nx, int(self.factor), nc, alpha=self.alpha, kappa=self.kappa, h=0.0,
-                             flow_direction=self.flowDirection, sampling=self.interpMethod, device=self.device)
+                             flow_direction=self.flowDirection, sampling=self.interpMethod if builtin else "taps",
+                             device=self.device)
+        if not builtin:
+            from .sampling import dim1_taps
+            try:
+                fy, wy = dim1_taps(Ny, ny, self.interpMethod, self.interpKernel, bool(self.interpAA))
+                fx, wx = dim1_taps(Nx, nx, self.interpMethod, self.interpKernel, bool(self.interpAA))
+            except NotImplementedError as e:
+                s.close()
+                raise MMCError(-4, str(e))
+            s.set_sampling_taps(fy, wy, fx, wx)
         s.set_lowres(self._imageSequenceSmall)
         s.set_blur(self.k)                                           # :373-375
         s.set_flow(v, self._occ)                                     # :389-412

@@ -15,7 +15,7 @@ from ._capi import MMCError, as_f32, fptr
 
 _DIRECTIONS = {"forward": _capi.FLOW_FORWARD, "backward": _capi.FLOW_BACKWARD,
                "forward-backward": _capi.FLOW_FORWARD_BACKWARD}
-_SAMPLINGS = {"average": _capi.SAMPLING_AVERAGE, "stride": _capi.SAMPLING_STRIDE}
+_SAMPLINGS = {"average": _capi.SAMPLING_AVERAGE, "stride": _capi.SAMPLING_STRIDE, "taps": _capi.SAMPLING_TAPS}
 
 
 class FrameBlockSolver(object):
@@ -27,8 +27,8 @@ class FrameBlockSolver(object):
         if flow_direction not in _DIRECTIONS:
             raise ValueError("Invalid flow direction.")
         if sampling not in _SAMPLINGS:
-            raise MMCError(-4, "interpMethod '%s' is not implemented by the HIP path "
-                               "(only 'average' and 'stride')" % sampling)
+            raise MMCError(-4, "sampling must be 'average', 'stride' or 'taps' (rows given with "
+                               "set_sampling_taps), got '%s'" % sampling)
         frame_end = nc_global if frame_end is None else frame_end
         p = _capi.mmc_params()
         p.size = C.sizeof(_capi.mmc_params)
@@ -98,6 +98,20 @@ class FrameBlockSolver(object):
             return
         k = as_f32(np.atleast_2d(k))
         self._check(self._lib.mmc_set_blur(self._h, fptr(k), k.shape[0], k.shape[1]))
+
+    def set_sampling_taps(self, first_y, w_y, first_x, w_x):
+        """1-D factors of the sampling operator in banded form (see sampling.dim1_taps)."""
+        fy = np.ascontiguousarray(first_y, dtype=np.int32)
+        fx = np.ascontiguousarray(first_x, dtype=np.int32)
+        wy = np.ascontiguousarray(w_y, dtype=np.float32)
+        wx = np.ascontiguousarray(w_x, dtype=np.float32)
+        if fy.shape != (self.ny,) or wy.ndim != 2 or wy.shape[0] != self.ny:
+            raise ValueError("row taps must be (%d,) and (%d, T)" % (self.ny, self.ny))
+        if fx.shape != (self.nx,) or wx.ndim != 2 or wx.shape[0] != self.nx:
+            raise ValueError("column taps must be (%d,) and (%d, T)" % (self.nx, self.nx))
+        i32 = C.POINTER(C.c_int32)
+        self._check(self._lib.mmc_set_sampling_taps(self._h, fy.ctypes.data_as(i32), fptr(wy), wy.shape[1],
+                                                    fx.ctypes.data_as(i32), fptr(wx), wx.shape[1]))
 
     def set_flow(self, v, occ=None):
         npairs = self.num_flow_pairs
