@@ -438,6 +438,17 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
     constexpr int LATE = MMC_LATE;
     own_loads(LATE < 1, LATE < 2, LATE < 3, LATE < 4);
 
+    // source boxes of the scatter below, fetched ahead of the barrier
+    int4 sbox[2] = {make_int4(0, -1, 0, -1), make_int4(0, -1, 0, -1)};
+    if (MODE != MODE_STEPS) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int q = which == 0 ? t - 1 : t;
+            if (pair_exists(g, q) && (which == 0) == pair_is_IF(g, q))
+                sbox[which] = *reinterpret_cast<const int4 *>(a.bbox + ((size_t)(q + 1) * g.ntiles + tile) * 4);
+        }
+    }
+
     for (int k = tid; k < TILE_R * TILE_C; k += MMC_THREADS) {
         acc1[k] = 0;
         if (MODEL == MODEL_IC) acc2[k] = 0;
@@ -462,8 +473,7 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
             if (!pair_exists(g, q)) continue;
             const bool isIF = pair_is_IF(g, q);
             if ((which == 0) != isIF) continue;
-            const int *bb = a.bbox + ((size_t)(q + 1) * g.ntiles + tile) * 4;
-            const int rmin = bb[0], rmax = bb[1], cmin = bb[2], cmax = bb[3];
+            const int rmin = sbox[which].x, rmax = sbox[which].y, cmin = sbox[which].z, cmax = sbox[which].w;
             if (rmax < rmin || cmax < cmin) continue;
             if (g.dbg & 1) continue;
             const int nr = rmax - rmin + 1, total = nr * (cmax - cmin + 1);
