@@ -463,6 +463,27 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
     }
     __syncthreads();
 
+    // The early loads have landed (the staging loads behind them have).  Fold them into the part
+    // of K'y that does not depend on the scatter, so that 8 instead of 34 registers stay live
+    // across it:  eu = kappa G'g1 - (1/h) Id'g1t,  ew = -kappa G'g1 + G'g2 - (1/h) Id'(kappa g2t - g1t).
+    float eu[4] = {0.f, 0.f, 0.f, 0.f}, ew[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != MODE_STEPS && active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool below = r + i < g.Ny - 1;
+            const float d1 = gl1[i] - (cr ? gx1[i] : 0.f) + (i > 0 ? gy1[i > 0 ? i - 1 : 0] : up1) - (below ? gy1[i] : 0.f);
+            eu[i] = kap * d1;
+            if (MODEL == MODEL_IC) {
+                const float d2 = gl2[i] - (cr ? gx2[i] : 0.f) + (i > 0 ? gy2[i > 0 ? i - 1 : 0] : up2) - (below ? gy2[i] : 0.f);
+                ew[i] = d2 - kap * d1;
+            }
+            if (idA) {
+                eu[i] -= g.inv_h * sA1[i];
+                if (MODEL == MODEL_IC) ew[i] -= g.inv_h * (kap * sA2[i] - sA1[i]);
+            }
+        }
+    }
+
     // --- scatter part of W': walk the source box of this tile ----------------
     // SCU source pixels per thread and pass, all their loads issued before the
     // first use so that one pass costs one memory round trip.
@@ -552,26 +573,13 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
                 Wt1[i] = from_fx(acc1[4 * rq + i + TILE_R * lc]);
                 if (MODEL == MODEL_IC) Wt2[i] = from_fx(acc2[4 * rq + i + TILE_R * lc]);
             }
-            // identity part of W': -g of the pairs whose -Id block sits on this frame
-            if (idA) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { Wt1[i] -= sA1[i]; if (MODEL == MODEL_IC) Wt2[i] -= kap * sA2[i] - sA1[i]; }
-            }
+            // identity part of W' of pair t-1 (that of pair t is already in eu, ew)
             if (idB) {
                 float s1[4], s2[4];
                 ld4(s1, FR(a.g1t, t - 1) + j);
                 if (MODEL == MODEL_IC) ld4(s2, FR(a.g2t, t - 1) + j);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { Wt1[i] -= s1[i]; if (MODEL == MODEL_IC) Wt2[i] -= kap * s2[i] - s1[i]; }
-            }
-            // G' of the spatial duals
-            float div1[4], div2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool below = r + i < g.Ny - 1;
-                div1[i] = gl1[i] - (cr ? gx1[i] : 0.f) + (i > 0 ? gy1[i > 0 ? i - 1 : 0] : up1) - (below ? gy1[i] : 0.f);
-                if (MODEL == MODEL_IC)
-                    div2[i] = gl2[i] - (cr ? gx2[i] : 0.f) + (i > 0 ? gy2[i > 0 ? i - 1 : 0] : up2) - (below ? gy2[i] : 0.f);
             }
             // A'p
             float ATp[4];
@@ -652,8 +660,8 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                KTu[i] = ATp[i] + g.inv_h * Wt1[i] + kap * div1[i];
-                KTw[i] = (MODEL == MODEL_IC) ? g.inv_h * Wt2[i] - kap * div1[i] + div2[i] : 0.f;
+                KTu[i] = ATp[i] + g.inv_h * Wt1[i] + eu[i];
+                KTw[i] = (MODEL == MODEL_IC) ? g.inv_h * Wt2[i] + ew[i] : 0.f;
             }
             if (isfix) {
                 float q1v[4], q2v[4];
