@@ -547,6 +547,23 @@ static int build_data_operator(mmc_handle *h) {
             sig[(size_t)R + (size_t)g.ny * C] = rowsum > 0.0 ? (float)(1.0 / rowsum) : 1.f;
         }
     std::vector<float> colf(colsum.begin(), colsum.end());
+    g.cA_margin = 0;
+    if (f == 4 && g.ny >= 2 && g.nx >= 2) {
+        const int rc = 4 * (g.ny / 2), cc = 4 * (g.nx / 2);
+        float vmax = 0.f;
+        for (int k = 0; k < 4; ++k)
+            for (int i = 0; i < 4; ++i) {
+                g.cA_tab[i + 4 * k] = colf[(size_t)(rc + i) + (size_t)g.Ny * (cc + k)];
+                vmax = std::max(vmax, g.cA_tab[i + 4 * k]);
+            }
+        int margin = 0;
+        for (int c = 0; c < g.Nx; ++c)
+            for (int r = 0; r < g.Ny; ++r)
+                if (std::fabs(colf[(size_t)r + (size_t)g.Ny * c] - g.cA_tab[(r & 3) + 4 * (c & 3)]) > 1e-7f * vmax)
+                    margin = std::max(margin, std::min(std::min(r, g.Ny - 1 - r), std::min(c, g.Nx - 1 - c)) + 1);
+        margin = (margin + 3) & ~3;
+        if (2 * margin + 4 <= g.Ny && 2 * margin + 1 <= g.Nx) g.cA_margin = std::max(margin, 4);
+    }
     HIPCHK(h, hipMemcpyAsync(h->a.cker, ckf.data(), ckf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->a.cA, colf.data(), colf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->a.sigp, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));

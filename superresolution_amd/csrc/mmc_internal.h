@@ -60,6 +60,11 @@ struct Geom {
     FastDiv dv_PR;
     float alpha, kappa, inv_h;
     float radius1, radius2;    // projection radii of the g1 / g2 groups
+    // Away from the frame border the column abs-sum of A repeats with period f in both directions.
+    // cA_margin > 0: pixels at least that far from every border take it from cA_tab (f = 4 only)
+    // instead of reading the cA plane.
+    int cA_margin;
+    float cA_tab[16];          // [row mod 4 + 4 * (column mod 4)]
     int fixed;                 // 1: first frame of the sequence is pinned to (u0, w0), MultiframeMotionCoupling.m:535-572
     int dbg;                   // ablation switches for kernel tuning (env MMC_DEBUG), 0 in production
 };

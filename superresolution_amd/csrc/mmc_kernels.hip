@@ -409,7 +409,15 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
         if (!active) return;
         if (grpX) {
             ld4(cWv, FR(a.cW, t) + j);
-            ld4(cAv, a.cA + j);
+            if (F == 4 && g.cA_margin > 0 && r >= g.cA_margin && r + 4 <= g.Ny - g.cA_margin &&
+                c >= g.cA_margin && c < g.Nx - g.cA_margin && !(g.dbg & 128)) {
+                // interior: period-4 pattern (row phase of quad row i is i)
+                const int cph = PHASED ? __builtin_amdgcn_readfirstlane(c & 3) : (c & 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cAv[i] = g.cA_tab[i + 4 * cph];
+            } else {
+                ld4(cAv, a.cA + j);
+            }
             if (MODE == MODE_UPDATE) {
                 ld4(uo, FR(a.u, t) + j);
                 if (MODEL == MODEL_IC) ld4(wo, FR(a.w, t) + j);
