@@ -80,20 +80,6 @@ __device__ __forceinline__ float sample(const Taps &t, const float *img) {
 // gfx950 whereas float LDS atomics take about 3 clocks per lane, integer sums do
 // not depend on arrival order (runs are bitwise reproducible), and 2^-40 is far
 // below float32 resolution for any |value| < 2^23.
-#ifndef MMC_SCU
-#define MMC_SCU 5
-#endif
-#ifndef MMC_FAST77
-#define MMC_FAST77 1
-#endif
-#ifndef MMC_LATE
-#define MMC_LATE 1
-#endif
-#ifndef MMC_P_WAVES
-#define MMC_P_ATTR
-#else
-#define MMC_P_ATTR __attribute__((amdgpu_waves_per_eu(MMC_P_WAVES, MMC_P_WAVES)))
-#endif
 typedef unsigned long long fx64;
 // round(w * s40) as a two's-complement integer, |w * s40| < 2^51: adding 1.5*2^52 in double
 // leaves the integer in the mantissa, so the bit pattern minus that of 1.5*2^52 is the result.
@@ -364,7 +350,7 @@ __device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
 }
 
 template <int MODEL, int MODE, bool REDUCE, int F>
-__global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arrays a, int t0, int nf) {
+__global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     fx64 *acc1 = reinterpret_cast<fx64 *>(lds);
     fx64 *acc2 = acc1 + TILE_R * TILE_C;
@@ -403,8 +389,10 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
     float gx1[4], gl1[4] = {0.f, 0.f, 0.f, 0.f}, gy1[4], up1 = 0.f;
     float gx2[4], gl2[4] = {0.f, 0.f, 0.f, 0.f}, gy2[4], up2 = 0.f;
     float sA1[4] = {0.f, 0.f, 0.f, 0.f}, sA2[4] = {0.f, 0.f, 0.f, 0.f};
-    // Loads of this thread's own quad, in four groups.  A group is issued either here, ahead of the
-    // scatter (it then occupies its registers across the scatter), or after it.
+    // Loads of this thread's own quad, in groups.  The dual planes (grp1, grp2, grpA) are issued
+    // here, ahead of the scatter, and are folded into eu / ew right after the staging barrier; the
+    // state and step-size planes (grpX) are issued after the scatter, where they are first needed
+    // (measured: fewer live registers across the scatter beats hiding their latency).
     auto own_loads = [&](bool grpX, bool grpA, bool grp2, bool grp1) {
         if (!active) return;
         if (grpX) {
@@ -443,8 +431,7 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
             if (MODEL == MODEL_IC) ld4(sA2, FR(a.g2t, t) + j);
         }
     };
-    constexpr int LATE = MMC_LATE;
-    own_loads(LATE < 1, LATE < 2, LATE < 3, LATE < 4);
+    own_loads(false, true, true, true);
 
     // source boxes of the scatter below, fetched ahead of the barrier
     int4 sbox[2] = {make_int4(0, -1, 0, -1), make_int4(0, -1, 0, -1)};
@@ -496,7 +483,7 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
     // SCU source pixels per thread and pass, all their loads issued before the
     // first use so that one pass costs one memory round trip.
     if (MODE != MODE_STEPS) {
-        constexpr int SCU = MMC_SCU;
+        constexpr int SCU = 5;
         for (int which = 0; which < 2; ++which) {
             const int q = which == 0 ? t - 1 : t;
             if (!pair_exists(g, q)) continue;
@@ -549,7 +536,7 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
         __syncthreads();
     }
 
-    own_loads(LATE >= 1, LATE >= 2, LATE >= 3, LATE >= 4);
+    own_loads(true, false, false, false);      // u, w, cW, cA: only needed from here on
     float part[2] = {0.f, 0.f};
     if (active) {
         float *u = FR(a.u, t) + j, *w = FR(a.w, t) + j, *ub = FR(a.ub, t) + j, *wb = FR(a.wb, t) + j;
@@ -598,7 +585,7 @@ __global__ __launch_bounds__(MMC_THREADS) MMC_P_ATTR void k_primal4(Geom g, Arra
             // The reference's default geometry (zoom 4, 7x7 blur: oy = ox = -3): kernel row phase and
             // low-res row of quad row i are fixed (x = r+i+3: phases 3,0,1,2; rows a,a+1,a+1,a+1 with
             // a = r/4), so the 4 x 3 low-res values sit in registers and the weights are scalars.
-            const bool fast77 = MMC_FAST77 && PHASED && j33 && g.oy == -3 && g.ox == -3 && !(g.dbg & 2048);
+            const bool fast77 = PHASED && j33 && g.oy == -3 && g.ox == -3 && !(g.dbg & 2048);
             const bool qborder = cborder || r == 0 || r + 4 >= g.Ny;      // the quad touches the frame border
             if (g.dbg & 4) {
 #pragma unroll
