@@ -161,7 +161,9 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
         g.dv_qlast = make_fastdiv((unsigned)(rest > 0 ? rest : q));
     }
     g.inv_h = 1.f;
+#ifdef MMC_ABLATION
     if (const char *e = getenv("MMC_DEBUG")) g.dbg = atoi(e);
+#endif
     if (p->h > 0.f) { h->h = p->h; h->have_h = true; g.inv_h = 1.f / p->h; }
 
     Arrays &a = h->a;

@@ -66,7 +66,7 @@ struct Geom {
     int cA_margin;
     float cA_tab[16];          // [row mod 4 + 4 * (column mod 4)]
     int fixed;                 // 1: first frame of the sequence is pinned to (u0, w0), MultiframeMotionCoupling.m:535-572
-    int dbg;                   // ablation switches for kernel tuning (env MMC_DEBUG), 0 in production
+    int dbg;                   // ablation switches for kernel tuning (env MMC_DEBUG); read only in -DMMC_ABLATION builds
 };
 
 // Every per-pixel array holds L+2 frames: slot 0 is the ghost of the previous

@@ -80,6 +80,13 @@ __device__ __forceinline__ float sample(const Taps &t, const float *img) {
 // gfx950 whereas float LDS atomics take about 3 clocks per lane, integer sums do
 // not depend on arrival order (runs are bitwise reproducible), and 2^-40 is far
 // below float32 resolution for any |value| < 2^23.
+// Ablation switches for kernel tuning (env MMC_DEBUG, see tools/build_variant.sh): compiled in
+// only with -DMMC_ABLATION; a regular build has none of these paths.
+#ifdef MMC_ABLATION
+#define ABL(bit) ((g.dbg & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
 typedef unsigned long long fx64;
 // round(w * s40) as a two's-complement integer, |w * s40| < 2^51: adding 1.5*2^52 in double
 // leaves the integer in the mantissa, so the bit pattern minus that of 1.5*2^52 is the result.
@@ -148,7 +155,7 @@ __device__ __forceinline__ void block_accumulate(float (&v)[NV], double *sums, i
 // round-robin tiles.  Placement only affects speed; surplus workgroups exit.
 __device__ __forceinline__ bool decode_block(const Geom &g, int nf, int &tile, int &trel) {
     const int b = blockIdx.x;
-    if (g.dbg & 32) { tile = b % g.ntiles; trel = b / g.ntiles; return trel < nf; }
+    if (ABL(32)) { tile = b % g.ntiles; trel = b / g.ntiles; return trel < nf; }
     const int x = b & 7, s = b >> 3;
     const int q = (g.ntiles + 7) >> 3;
     const int lo = x * q, cnt = min(q, g.ntiles - lo);
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
         if (grpX) {
             ld4(cWv, FR(a.cW, t) + j);
             if (F == 4 && g.cA_margin > 0 && r >= g.cA_margin && r + 4 <= g.Ny - g.cA_margin &&
-                c >= g.cA_margin && c < g.Nx - g.cA_margin && !(g.dbg & 128)) {
+                c >= g.cA_margin && c < g.Nx - g.cA_margin && !ABL(128)) {
                 // interior: period-4 pattern (row phase of quad row i is i)
                 const int cph = PHASED ? __builtin_amdgcn_readfirstlane(c & 3) : (c & 3);
 #pragma unroll
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             if ((which == 0) != isIF) continue;
             const int rmin = sbox[which].x, rmax = sbox[which].y, cmin = sbox[which].z, cmax = sbox[which].w;
             if (rmax < rmin || cmax < cmin) continue;
-            if (g.dbg & 1) continue;
+            if (ABL(1)) continue;
             const int nr = rmax - rmin + 1, total = nr * (cmax - cmin + 1);
             const float inv_nr = fast_rcp((float)nr);
             const float *vx = FR(a.vx, q), *vy = FR(a.vy, q);
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
                     const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
                     const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
                     const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
-                    if (g.dbg & 2) { if (s1 == 12345.f && ra0 && cb1) acc1[0] = to_fx(1.0, d2); continue; }
+                    if (ABL(2)) { if (s1 == 12345.f && ra0 && cb1) acc1[0] = to_fx(1.0, d2); continue; }
                     if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00, d2); }
                     if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10, d2); }
                     if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01, d2); }
@@ -585,9 +592,9 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             // The reference's default geometry (zoom 4, 7x7 blur: oy = ox = -3): kernel row phase and
             // low-res row of quad row i are fixed (x = r+i+3: phases 3,0,1,2; rows a,a+1,a+1,a+1 with
             // a = r/4), so the 4 x 3 low-res values sit in registers and the weights are scalars.
-            const bool fast77 = PHASED && j33 && g.oy == -3 && g.ox == -3 && !(g.dbg & 2048);
+            const bool fast77 = PHASED && j33 && g.oy == -3 && g.ox == -3 && !ABL(2048);
             const bool qborder = cborder || r == 0 || r + 4 >= g.Ny;      // the quad touches the frame border
-            if (g.dbg & 4) {
+            if (ABL(4)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ATp[i] = 0.f;
             } else if (fast77 && !qborder) {
@@ -910,7 +917,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     const bool isIF = pair_is_IF(g, t);
     // Zoom 4: the window starts on a row quad (g.wpad extra rows on top, height g.SRp), so that it
     // is staged with 16-byte loads and each low-res pixel reads its kernel rows as aligned float4.
-    const bool VEC = F == 4 && g.SRp <= 128 && !(g.dbg & 4096);
+    const bool VEC = F == 4 && g.SRp <= 128 && !ABL(4096);
     const int SR = VEC ? g.SRp : TILE_R + g.CH - f, SC = TILE_C + g.CW - f;
     const int wpad = VEC ? g.wpad : 0;
     const int LRR = TILE_R / f, LRC = TILE_C / f, nlr = LRR * LRC;
@@ -927,7 +934,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     // per pixel are LDS reads; otherwise (violent flow) they are gathered from global memory.
     int wrlo = 0, wclo = 0, WR = 0, WC = 0;
     bool use_lds = false;
-    if (pex && MODE != MODE_STEPS && !(g.dbg & 1024)) {
+    if (pex && MODE != MODE_STEPS && !ABL(1024)) {
         const int *tb = a.tbox + ((size_t)t * g.ntiles + tile) * 4;
         if (tb[1] >= tb[0]) {
             wrlo = tb[0] & ~3;
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     }
 
     // stage the xbar_u window, replicate border (helpers/RepConvMtx.m:23-32)
-    if (MODE != MODE_STEPS && !(g.dbg & 512)) {
+    if (MODE != MODE_STEPS && !ABL(512)) {
         const int wr0 = r0 + g.oy - wpad, wc0 = c0 + g.ox;
         if (VEC) {
             for (int k = tid; k < g.MPq * g.CW; k += MMC_THREADS) ckq[k] = a.ckq[k];
@@ -1022,7 +1029,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
             const float wy = i < 3 ? wc[i < 3 ? i + 1 : 3] : wbelow;
             float tu = 0.f, tw = 0.f;
             valid[i] = false;
-            if (pex && !(g.dbg & 256)) {
+            if (pex && !ABL(256)) {
                 Taps tp = make_taps(g, r + i, c, fvx[i], fvy[i]);
                 valid[i] = tp.valid;
                 if (tp.valid) {
@@ -1144,7 +1151,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
 
     // ---- data term: p <- clamp(p + s (A xbar_u - f), -1, 1)   (:496) --------
     float epart = 0.f;
-    if (MODE != MODE_STEPS && !(g.dbg & 512)) {
+    if (MODE != MODE_STEPS && !ABL(512)) {
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         for (int lp = lane; lp < nlr; lp += 64) {
             const int Rl = lp % LRR, Cl = lp / LRR;
@@ -1418,7 +1425,7 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
         const int total = a.ne * nf;
         hipLaunchKernelGGL(k_corr_p, dim3((total + MMC_THREADS - 1) / MMC_THREADS), dim3(MMC_THREADS), 0, s, g, a, t0, nf);
     }
-    if (g.Ny % 4 == 0 && TILE_R % g.f == 0 && TILE_C % g.f == 0 && !(g.dbg & 16)) {
+    if (g.Ny % 4 == 0 && TILE_R % g.f == 0 && TILE_C % g.f == 0 && !ABL(16)) {
         // fused row-quad kernel: regulariser duals and data-term dual in one launch
         if (g.f == 4) launch_dual4<4>(g, a, t0, nf, mode, reduce, s);
         else launch_dual4<0>(g, a, t0, nf, mode, reduce, s);
