@@ -7,7 +7,7 @@ library has not been built.
 """
 from ._capi import MMCError  # noqa: F401
 
-__all__ = ["MMCError", "FrameBlockSolver", "MultiframeMotionCoupling"]
+__all__ = ["MMCError", "FrameBlockSolver", "MultiframeMotionCoupling", "MultiframeMotionCouplingAlternating"]
 
 
 def __getattr__(name):
@@ -17,4 +17,7 @@ def __getattr__(name):
     if name == "MultiframeMotionCoupling":
         from .mmc import MultiframeMotionCoupling
         return MultiframeMotionCoupling
+    if name == "MultiframeMotionCouplingAlternating":
+        from .alternating import MultiframeMotionCouplingAlternating
+        return MultiframeMotionCouplingAlternating
     raise AttributeError(name)
