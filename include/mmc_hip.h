@@ -206,9 +206,9 @@ int mmc_sync(mmc_handle *h);
  * stream around every launch (the reference only has tic/toc around run,
  * testfile.m:66-68).  With profiling enabled the next mmc_solve times up to
  * the first 512 iterations; mmc_get_profile then returns the average
- * duration in milliseconds of [0] the primal sweep kernel, [1] the dual
- * (regulariser) kernel, [2] the dual (data term) kernel, and the number of
- * iterations averaged. */
+ * duration in milliseconds of [0] the primal sweep, [1] the dual sweep
+ * (regulariser and data term), [2] always 0 (kept for layout), and the number
+ * of iterations averaged.  One event is recorded between consecutive sweeps. */
 int mmc_set_profiling(mmc_handle *h, int enable);
 int mmc_get_profile(mmc_handle *h, double out_ms[3], int *iterations);
 /* The same for a block driven through mmc_sweep_primal / mmc_sweep_dual: summed

@@ -826,7 +826,8 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
     const Geom &g = h->g;
     int prof_n = 0;
     if (h->profiling) {
-        const size_t need = (size_t)4 * std::min(max_iters, (int)PROF_MAX_ITERS);
+        // one event between consecutive sweeps: e[0] P e[1] D e[2] P e[3] D ...
+        const size_t need = (size_t)2 * std::min(max_iters, (int)PROF_MAX_ITERS) + 1;
         while (h->events.size() < need) {
             hipEvent_t e;
             HIPCHK(h, hipEventCreate(&e));
@@ -837,12 +838,12 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
         const bool check = ((it + 1) % check_every == 0) || it == max_iters - 1;
         if (check && (rc = zero_sums(h))) return rc;
         const bool prof = h->profiling && it < PROF_MAX_ITERS;
-        hipEvent_t *ev = prof ? &h->events[(size_t)4 * it] : nullptr;
-        if (prof) HIPCHK(h, hipEventRecord(ev[0], h->stream));
+        hipEvent_t *ev = prof ? &h->events[(size_t)2 * it] : nullptr;
+        if (prof && it == 0) HIPCHK(h, hipEventRecord(ev[0], h->stream));
         HIPCHK(h, mmc_launch_primal(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream));
         if (prof) HIPCHK(h, hipEventRecord(ev[1], h->stream));
-        HIPCHK(h, mmc_launch_dual(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream, prof ? ev[2] : nullptr));
-        if (prof) { HIPCHK(h, hipEventRecord(ev[3], h->stream)); prof_n = it + 1; }
+        HIPCHK(h, mmc_launch_dual(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream));
+        if (prof) { HIPCHK(h, hipEventRecord(ev[2], h->stream)); prof_n = it + 1; }
         st.iterations = it + 1;
         if (check) {
             double s[MMC_NUM_SUMS];
@@ -857,10 +858,10 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
     st.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (h->profiling) {
         prof_n = std::min(prof_n, st.iterations);
-        double acc[3] = {0, 0, 0};
+        double acc[3] = {0, 0, 0};      // primal sweep, dual sweep, (unused)
         for (int it = 0; it < prof_n; ++it) {
-            hipEvent_t *ev = &h->events[(size_t)4 * it];
-            for (int k = 0; k < 3; ++k) {
+            hipEvent_t *ev = &h->events[(size_t)2 * it];
+            for (int k = 0; k < 2; ++k) {
                 float ms = 0.f;
                 HIPCHK(h, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
                 acc[k] += ms;
