@@ -175,6 +175,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
         if (rc != MMC_OK) return bail(rc);
     }
     int rc;
+    if ((rc = dev_alloc(h, &a.idq, (size_t)h->L * ((size_t)g.N / 4 + 1))) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.p, (size_t)h->L * g.n)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.f, (size_t)h->L * g.n)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.cA, (size_t)g.N)) != MMC_OK) return bail(rc);

@@ -79,6 +79,7 @@ struct Arrays {
     float *g2t, *g2x, *g2y;    // dual of K2
     float *vx, *vy;            // flow of pair t (frame t <-> t+1); NaN = masked
     float *cW;                 // column abs-sum of the motion-coupling operator
+    uint8_t *idq;              // per local frame and row quad: 2 bits per row = number of unmasked -Id entries of W in that column (the part of cW that is not scattered)
     float *q1, *q2;            // duals of the first-frame constraint u_1 = u0, w_1 = w0 (one frame each)
     float *u0, *w0;            // the pinned first frame
     float *p, *f;              // data-term dual and low-res data, L*n

@@ -87,6 +87,9 @@ __device__ __forceinline__ float sample(const Taps &t, const float *img) {
 #else
 #define ABL(bit) false
 #endif
+#ifndef MMC_CW_SCATTER
+#define MMC_CW_SCATTER 1
+#endif
 typedef unsigned long long fx64;
 // round(w * s40) as a two's-complement integer, |w * s40| < 2^51: adding 1.5*2^52 in double
 // leaves the integer in the mantissa, so the bit pattern minus that of 1.5*2^52 is the result.
@@ -359,9 +362,13 @@ __device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
 template <int MODEL, int MODE, bool REDUCE, int F>
 __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
+    // In the update sweep the tap weights are scattered along with the duals, which yields the
+    // scattered part of cW without reading the cW plane (4 bytes per pixel less).
+    constexpr bool CWS = MMC_CW_SCATTER && MODE == MODE_UPDATE;
     fx64 *acc1 = reinterpret_cast<fx64 *>(lds);
     fx64 *acc2 = acc1 + TILE_R * TILE_C;
-    float *ckp = lds + 4 * TILE_R * TILE_C;
+    fx64 *acc3 = acc2 + TILE_R * TILE_C;
+    float *ckp = lds + 6 * TILE_R * TILE_C;
     float *pl = ckp + ((g.MP * g.NP + 3) & ~3);
     const int f = F > 0 ? F : g.f;
     const int tid = threadIdx.x;
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     auto own_loads = [&](bool grpX, bool grpA, bool grp2, bool grp1) {
         if (!active) return;
         if (grpX) {
-            ld4(cWv, FR(a.cW, t) + j);
+            if (!CWS) ld4(cWv, FR(a.cW, t) + j);
             if (F == 4 && g.cA_margin > 0 && r >= g.cA_margin && r + 4 <= g.Ny - g.cA_margin &&
                 c >= g.cA_margin && c < g.Nx - g.cA_margin && !ABL(128)) {
                 // interior: period-4 pattern (row phase of quad row i is i)
@@ -454,6 +461,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     for (int k = tid; k < TILE_R * TILE_C; k += MMC_THREADS) {
         acc1[k] = 0;
         if (MODEL == MODEL_IC) acc2[k] = 0;
+        if (CWS) acc3[k] = 0;
     }
     if (MODE != MODE_STEPS) {
         for (int k = tid; k < g.MP * g.NP; k += MMC_THREADS) ckp[k] = a.ckp[k];
@@ -533,10 +541,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
                     const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
                     const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
                     if (ABL(2)) { if (s1 == 12345.f && ra0 && cb1) acc1[0] = to_fx(1.0, d2); continue; }
-                    if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00, d2); }
-                    if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10, d2); }
-                    if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01, d2); }
-                    if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11, d2); }
+                    if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00, d2); if (CWS) fx_add(&acc3[a0 + TILE_R * b0], tp.w00, 1099511627776.0); }
+                    if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10, d2); if (CWS) fx_add(&acc3[a1 + TILE_R * b0], tp.w10, 1099511627776.0); }
+                    if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01, d2); if (CWS) fx_add(&acc3[a0 + TILE_R * b1], tp.w01, 1099511627776.0); }
+                    if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11, d2); if (CWS) fx_add(&acc3[a1 + TILE_R * b1], tp.w11, 1099511627776.0); }
                 }
             }
         }
@@ -550,6 +558,11 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
         float tau_u[4], tau_w[4];
         const bool isfix = MODEL == MODEL_IC && g.fixed && g.frame_begin + t == 0;   // identity rows of q1, q2 (:560-561)
         const float fixc = isfix ? 1.f : 0.f;
+        if (CWS) {
+            const unsigned idb = a.idq[(size_t)t * (g.N / 4 + 1) + (j >> 2)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cWv[i] = from_fx(acc3[4 * rq + i + TILE_R * lc]) + (float)((idb >> (2 * i)) & 3u);
+        }
         auto compute_tau = [&]() {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1274,6 +1287,24 @@ __global__ __launch_bounds__(MMC_THREADS) void k_init_finalize(Geom g, Arrays a,
     FR(a.cW, t)[j] = s;
 }
 
+// Per row quad of frame t: how many unmasked -Id entries of W sit in each of its four columns
+// of the operator (0, 1 or 2), two bits per row.  With the scattered tap weights this is cW.
+__global__ __launch_bounds__(MMC_THREADS) void k_init_idq(Geom g, Arrays a, int t) {
+    const int qi = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (qi >= g.N / 4) return;
+    const int j = 4 * qi, r = j % g.Ny, c = j / g.Ny;
+    const bool useA = pair_exists(g, t) && pair_is_IF(g, t);
+    const bool useB = pair_exists(g, t - 1) && !pair_is_IF(g, t - 1);
+    unsigned bits = 0;
+    for (int i = 0; i < 4; ++i) {
+        unsigned n = 0;
+        if (useA && make_taps(g, r + i, c, FR(a.vx, t)[j + i], FR(a.vy, t)[j + i]).valid) ++n;
+        if (useB && make_taps(g, r + i, c, FR(a.vx, t - 1)[j + i], FR(a.vy, t - 1)[j + i]).valid) ++n;
+        bits |= n << (2 * i);
+    }
+    a.idq[(size_t)t * (g.N / 4 + 1) + qi] = (uint8_t)bits;
+}
+
 // Per (pair, tile): rows and columns of the warped frame touched by the taps of the tile's pixels.
 __global__ __launch_bounds__(MMC_THREADS) void k_init_tapbox(Geom g, Arrays a) {
     __shared__ int box[4];
@@ -1355,7 +1386,7 @@ static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int 
 template <int MODEL, int F>
 static void launch_primal4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
-    const size_t lds = (size_t)(4 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float);
+    const size_t lds = (size_t)(6 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0, nf);
@@ -1457,6 +1488,8 @@ hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *scratch, h
         if (exists(t - 1) && is_if(t - 1)) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, t - 1, tmp);
         if (exists(t) && !is_if(t)) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, t, tmp);
         hipLaunchKernelGGL(k_init_finalize, grid, block, 0, s, g, a, t, tmp);
+        if (g.Ny % 4 == 0)
+            hipLaunchKernelGGL(k_init_idq, dim3((g.N / 4 + MMC_THREADS - 1) / MMC_THREADS), block, 0, s, g, a, t);
     }
     hipLaunchKernelGGL(k_init_tapbox, dim3(g.ntiles, g.L), block, 0, s, g, a);
     return hipGetLastError();
