@@ -92,3 +92,21 @@ def test_solve_parity_violent_flow():
     f, v, occ = make_case(32, 40, 24, 3, flow="random", flow_scale=12.0)
     P, x, chg, u_ref, w_ref, u, w, st, e = _run(f, v, occ, 0.25, "forward-backward", 40)
     assert rel_l2(u, u_ref) < TOL
+
+
+@pytest.mark.parametrize("factor,ny,nx", [(2, 14, 18), (3, 7, 8)])
+def test_solve_parity_other_zoom_factors(factor, ny, nx):
+    """Update sweeps of the generic-factor row-quad kernels (zoom 2) and of the scalar kernels
+    (zoom 3: the row count is not a multiple of 4), 'stride' sampling with a 5x5 blur."""
+    from superresolution_amd.solver import FrameBlockSolver
+    f, v, _ = make_case(33, ny, nx, 3, factor=factor, flow="smooth", flow_scale=1.5)
+    k = orc.fspecial_gaussian(5, 1.0)
+    P = orc.build_problem(f, v, factor=factor, k=k, interpMethod="stride")
+    x, y, chg = orc.pdhg(P, 80)
+    u_ref, w_ref = orc.split_primal(P, x)
+    s = FrameBlockSolver(ny, nx, factor, 3, alpha=P.alpha, kappa=0.25, h=0.0, sampling="stride")
+    s.set_lowres(f); s.set_blur(k); s.set_flow(v); s.set_state(P.u_up, P.u_up); s.init()
+    s.solve(80, 0.0, 0)
+    u, w = s.get_state()
+    s.close()
+    assert rel_l2(u, u_ref) < TOL
