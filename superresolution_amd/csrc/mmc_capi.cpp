@@ -159,6 +159,12 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
         g.dv_tiles_r = make_fastdiv((unsigned)g.tiles_r);
         g.dv_q = make_fastdiv((unsigned)q);
         g.dv_qlast = make_fastdiv((unsigned)(rest > 0 ? rest : q));
+        // The second use of a frame's planes (scatter sources, warp taps) comes one sweep over the
+        // range later; keeping a range near 290 tiles per class (what a 1080p frame has) keeps that
+        // distance inside the Infinity Cache for larger frames as well.
+        const int nsub = (q + 287) / 288;
+        g.chunk = nsub > 1 ? (q + nsub - 1) / nsub : 0;
+        g.dv_chunk = make_fastdiv((unsigned)(g.chunk > 0 ? g.chunk : 1));
     }
     g.inv_h = 1.f;
 #ifdef MMC_ABLATION

@@ -58,6 +58,10 @@ struct Geom {
     FastDiv dv_tiles_r;        // tile -> (tile row, tile column)
     FastDiv dv_q, dv_qlast;    // tiles per XCD class ((ntiles+7)/8) and of the last non-empty class
     FastDiv dv_PR;
+    // Frames larger than about 2 Mpx: each XCD class walks its tile range in sub-ranges of `chunk`
+    // tiles, every sub-range through all frames of the launch before the next one (0: one range).
+    int chunk;
+    FastDiv dv_chunk, dv_per;  // dv_per: chunk * (frames of this launch), set by the launcher
     float alpha, kappa, inv_h;
     float radius1, radius2;    // projection radii of the g1 / g2 groups
     // Away from the frame border the column abs-sum of A repeats with period f in both directions.

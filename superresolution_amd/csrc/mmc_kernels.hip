@@ -163,6 +163,13 @@ __device__ __forceinline__ bool decode_block(const Geom &g, int nf, int &tile, i
     const int q = (g.ntiles + 7) >> 3;
     const int lo = x * q, cnt = min(q, g.ntiles - lo);
     if (cnt <= 0 || s >= cnt * nf) return false;
+    if (g.chunk > 0) {
+        const int grp = fdiv(s, g.dv_per), rem = s - grp * (g.chunk * nf);
+        const int sg = min(g.chunk, cnt - grp * g.chunk);
+        trel = sg == g.chunk ? fdiv(rem, g.dv_chunk) : rem / sg;
+        tile = lo + grp * g.chunk + (rem - trel * sg);
+        return true;
+    }
     trel = fdiv(s, cnt == q ? g.dv_q : g.dv_qlast);
     tile = lo + (s - trel * cnt);
     return true;
@@ -1383,8 +1390,16 @@ static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int 
     else hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
 }
 
+// The block decode divides by chunk * (frames of the launch); the magic number goes in with the launch.
+static Geom with_launch_frames(const Geom &g0, int nf) {
+    Geom g = g0;
+    g.dv_per = make_fastdiv((unsigned)((g.chunk > 0 ? g.chunk : 1) * nf));
+    return g;
+}
+
 template <int MODEL, int F>
-static void launch_primal4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+static void launch_primal4_m(const Geom &g0, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+    const Geom g = with_launch_frames(g0, nf);
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const size_t lds = (size_t)(6 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
@@ -1428,7 +1443,8 @@ static void launch_dual_m(const Geom &g, const Arrays &a, int t0, int nf, int mo
 }
 
 template <int MODEL, int F>
-static void launch_dual4_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+static void launch_dual4_m(const Geom &g0, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
+    const Geom g = with_launch_frames(g0, nf);
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const int f = g.f;
     const int SRmax = g.SRp > TILE_R + g.CH - f ? g.SRp : TILE_R + g.CH - f;
