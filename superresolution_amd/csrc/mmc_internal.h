@@ -106,9 +106,7 @@ struct Arrays {
 
 // Launchers (all asynchronous on `s`; return hipGetLastError()).
 hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s);
-// `mid`, when given, is recorded between the regulariser kernel and the data-term kernel.
-hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s,
-                           hipEvent_t mid = nullptr);
+hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s);
 // `scratch`: N 8-byte words of device memory
 hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *scratch, hipStream_t s);
 hipError_t mmc_launch_sanitize(const Geom &g, const Arrays &a, hipStream_t s);

@@ -1468,8 +1468,7 @@ static void launch_dual4(const Geom &g, const Arrays &a, int t0, int nf, int mod
     else launch_dual4_m<MODEL_ADD, F>(g, a, t0, nf, mode, reduce, s);
 }
 
-hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s,
-                           hipEvent_t mid) {
+hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s) {
     if (t1 <= t0) return hipSuccess;
     const int nf = t1 - t0;
     if (a.ne > 0 && mode != MODE_STEPS) {
@@ -1480,13 +1479,11 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
         // fused row-quad kernel: regulariser duals and data-term dual in one launch
         if (g.f == 4) launch_dual4<4>(g, a, t0, nf, mode, reduce, s);
         else launch_dual4<0>(g, a, t0, nf, mode, reduce, s);
-        if (mid) (void)hipEventRecord(mid, s);
         return hipGetLastError();
     }
     if (g.model == MODEL_IC) launch_dual_m<MODEL_IC>(g, a, t0, nf, mode, reduce, s);
     else if (g.model == MODEL_K1) launch_dual_m<MODEL_K1>(g, a, t0, nf, mode, reduce, s);
     else launch_dual_m<MODEL_ADD>(g, a, t0, nf, mode, reduce, s);
-    if (mid) (void)hipEventRecord(mid, s);
     const size_t total = (size_t)g.n * nf;
     dim3 gridp((unsigned)((total + MMC_THREADS - 1) / MMC_THREADS)), block(MMC_THREADS);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual_p<MODE_RAW, false>), gridp, block, 0, s, g, a, t0, nf);
