@@ -90,3 +90,50 @@ def test_block_solve_entry_point_refuses_blocks_with_neighbours():
         blocks[0].solve(5)
     for b in blocks:
         b.close()
+
+
+def test_blocks_with_a_generic_sampler():
+    """Frame blocks with a sampler given by taps (bicubic with antialiasing): the sparse border rows
+    and their per-frame correction planes are indexed by local frames in every block."""
+    import torch
+    from superresolution_amd import sharding
+    from superresolution_amd.sampling import dim1_taps
+    from superresolution_amd.solver import FrameBlockSolver
+    nc, iters = 4, 30
+    ny, nx = 10, 9
+    f, v, _ = make_case(19, ny, nx, nc, flow="smooth", flow_scale=1.5)
+    P = orc.build_problem(f, v, k=KBLUR, interpMethod="bicubic", interpAA=True)
+    x_ref, _, _ = orc.pdhg(P, iters)
+    u_ref, _ = orc.split_primal(P, x_ref)
+    fy, wy = dim1_taps(4 * ny, ny, "bicubic", None, True)
+    fx, wx = dim1_taps(4 * nx, nx, "bicubic", None, True)
+    blocks = []
+    for a, b in [(0, 1), (1, 4)]:
+        s = FrameBlockSolver(ny, nx, 4, nc, a, b, alpha=P.alpha, kappa=0.25, h=P.h, sampling="taps")
+        lo, hi = sharding.pairs_needed(a, b, nc)
+        s0, s1 = sharding.state_frames_needed(a, b, nc)
+        s.set_sampling_taps(fy, wy, fx, wx)
+        s.set_lowres(f[:, :, a:b]); s.set_blur(KBLUR); s.set_flow(v[:, :, lo:hi, :])
+        s.set_state(P.u_up[:, :, s0:s1], P.u_up[:, :, s0:s1]); s.init()
+        blocks.append(s)
+    halos = [sharding.halo_tensors(b) for b in blocks]
+
+    def exchange(src_key, dst_key, i_src, i_dst):
+        for b in blocks:
+            b.sync()
+        for k in range(2):
+            if halos[i_src][src_key][k] is not None:
+                halos[i_dst][dst_key][k].copy_(halos[i_src][src_key][k])
+        torch.cuda.synchronize()
+
+    for it in range(iters):
+        for b in blocks:
+            b.sweep_primal(0, b.L, False)
+        exchange("send_prev", "recv_next", 1, 0)
+        for b in blocks:
+            b.sweep_dual(0, b.L, False)
+        exchange("send_next", "recv_prev", 0, 1)
+    u = np.concatenate([b.get_state()[0] for b in blocks], axis=2)
+    assert rel_l2(u, u_ref) < 1e-4
+    for b in blocks:
+        b.close()
