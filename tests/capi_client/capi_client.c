@@ -8,13 +8,31 @@
  *          then uint8 occ[Ny*Nx*(nc-1)] if have_occ
  * out.bin: float32 u[Ny*Nx*nc], w[Ny*Nx*nc], float64 {h, res_primal, res_dual, energy}
  */
+#define _GNU_SOURCE
+#include <execinfo.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include "../../include/mmc_hip.h"
+
+/* Last call entered, and a backtrace on a fatal signal: a crash inside the library or the HIP
+ * runtime then names its place in the test log instead of a bare exit status. */
+static const char *volatile g_phase = "start";
+static void on_fatal(int sig) {
+    void *bt[64];
+    const char *msg = "capi_client: fatal signal in phase: ";
+    if (write(2, msg, strlen(msg)) < 0) _exit(128 + sig);
+    if (write(2, g_phase, strlen(g_phase)) < 0 || write(2, "\n", 1) < 0) _exit(128 + sig);
+    backtrace_symbols_fd(bt, backtrace(bt, 64), 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
 
 #define CHECK(call)                                                                   \
     do {                                                                              \
+        g_phase = #call;                                                              \
         int rc_ = (call);                                                             \
         if (rc_ != MMC_OK) {                                                          \
             fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, mmc_last_error(h));   \
@@ -29,6 +47,9 @@ static void *read_block(FILE *fp, size_t bytes) {
 }
 
 int main(int argc, char **argv) {
+    signal(SIGSEGV, on_fatal);
+    signal(SIGBUS, on_fatal);
+    signal(SIGABRT, on_fatal);
     if (argc != 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 1; }
     FILE *fp = fopen(argv[1], "rb");
     if (!fp) { perror(argv[1]); return 1; }
@@ -75,6 +96,7 @@ int main(int argc, char **argv) {
     double energy = 0.0;
     CHECK(mmc_energy(h, &energy));
     CHECK(mmc_destroy(h));
+    g_phase = "after mmc_destroy";
 
     FILE *out = fopen(argv[2], "wb");
     if (!out) { perror(argv[2]); return 1; }
