@@ -183,6 +183,28 @@ int mmc_h_partials(mmc_handle *h, double out[2]);
 int mmc_set_h(mmc_handle *h, float value);
 int mmc_get_h(const mmc_handle *h, float *value);
 
+/* The two sums of mmc_h_partials for a whole sequence that already lives in device memory,
+ * without a handle and without allocating anything (no hipMalloc / hipFree, no host allocation).
+ * No counterpart in the reference.  It exists for callers that cannot allocate: code under HIP
+ * graph capture, tight serving loops that recompute h for every incoming batch, harnesses that
+ * forbid allocation after start-up.
+ *   d_u  Ny x Nx x nc        device, the frames (the bicubic start point, :415-419)
+ *   d_v  Ny x Nx x (nc-1) x 2 device, flows laid out as for mmc_set_flow; a NaN in either
+ *        component masks the row (fold an occlusion map in beforehand); may be NULL when nc == 1
+ *   d_out 2 doubles          device: [0] = sum |W u|, [1] = sum |grad u|
+ * Both kernels are queued on `stream` (a hipStream_t, NULL = the default stream) of `device`;
+ * the call does not synchronise, d_out is valid once the stream has passed it.  The per-workgroup
+ * partial sums live in a static device array of 8 MiB that each GPU used holds until the process
+ * ends: ceil(Ny*Nx/256)*nc must not exceed MMC_STATIC_MAX_BLOCKS (30 frames of 1080p need
+ * 243000, 15 frames of 2160x3840 need 486000); larger inputs are rejected with
+ * MMC_ERR_INVALID_ARG before anything is launched (mmc_last_error(NULL) has the text).  All
+ * calls on one GPU share that array: calls that overlap on one GPU (different streams or threads)
+ * race and must be serialised by the caller.  The sums are added in a fixed order, so the result
+ * is bitwise reproducible; it agrees with mmc_h_partials up to the rounding of double additions. */
+#define MMC_STATIC_MAX_BLOCKS 524288
+int mmc_h_partials_static(const float *d_u, const float *d_v, int Ny, int Nx, int nc,
+                          int flow_direction, int device, void *stream, double *d_out);
+
 /* The solve: prost.solve / flexBox.runAlgorithm, MultiframeMotionCoupling.m:981,
  * :989.  Runs at most max_iters PDHG iterations; every check_every iterations
  * (and after the last) the residuals are reduced, the callback runs, and the

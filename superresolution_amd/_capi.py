@@ -14,6 +14,7 @@ from .build import LIB_PATH
 
 MMC_ABI_VERSION = 2
 MMC_NUM_SUMS = 4
+MMC_STATIC_MAX_BLOCKS = 524288
 
 FLOW_FORWARD, FLOW_BACKWARD, FLOW_FORWARD_BACKWARD = 0, 1, 2
 SAMPLING_AVERAGE, SAMPLING_STRIDE, SAMPLING_TAPS = 0, 1, 2
@@ -74,6 +75,8 @@ SIGNATURES = {
     "mmc_h_partials": (C.c_int, [_H, _dp]),
     "mmc_set_h": (C.c_int, [_H, C.c_float]),
     "mmc_get_h": (C.c_int, [_H, _fp]),
+    "mmc_h_partials_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
     "mmc_solve": (C.c_int, [_H, C.c_int, C.c_float, C.c_int, C.POINTER(mmc_stats), PROGRESS_CB, C.c_void_p]),
     "mmc_sweep_primal": (C.c_int, [_H, C.c_int, C.c_int, C.c_int]),
     "mmc_sweep_dual": (C.c_int, [_H, C.c_int, C.c_int, C.c_int]),

@@ -49,9 +49,15 @@ struct mmc_handle {
 enum { PROF_MAX_ITERS = 512 };
 
 static thread_local std::string g_create_err;
+static thread_local const char *g_static_err = nullptr;   // set by handle-free entry points, cleared by mmc_create
 
 static int fail(mmc_handle *h, int code, const std::string &msg) {
-    if (h) h->err = msg; else g_create_err = msg;
+    if (h) h->err = msg; else { g_create_err = msg; g_static_err = nullptr; }
+    return code;
+}
+
+int mmc_static_fail(int code, const char *literal) {
+    g_static_err = literal;
     return code;
 }
 
@@ -80,7 +86,8 @@ static int dev_alloc(mmc_handle *h, T **ptr, size_t count, bool zero = true) {
 extern "C" int mmc_abi_version(void) { return MMC_ABI_VERSION; }
 
 extern "C" const char *mmc_last_error(const mmc_handle *h) {
-    return h ? h->err.c_str() : g_create_err.c_str();
+    if (h) return h->err.c_str();
+    return g_static_err ? g_static_err : g_create_err.c_str();
 }
 
 extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {

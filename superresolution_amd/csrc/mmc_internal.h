@@ -26,6 +26,7 @@ enum { MMC_MAX_CK = 40 };      // max side of the composite (sampling * blur) ke
 enum { MMC_WARP_MAX = 2304 }; // floats of the warped frame a tile may stage in LDS per plane
 enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
 enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device
+// MMC_STATIC_MAX_BLOCKS (public header): workgroups of k_h_partials that mmc_h_partials_static has room for
 
 // Division of 0 <= n < 2^31 by a fixed d through one high multiply: n / d = umulhi(n, m) >> s
 // with m = ceil(2^(31+l) / d), s = l - 1, l = ceil(log2 d); d = 1 is flagged by m = 0.
@@ -107,8 +108,12 @@ struct Arrays {
 // Launchers (all asynchronous on `s`; return hipGetLastError()).
 hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s);
 hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s);
-// `scratch`: N 8-byte words of device memory
-hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *scratch, hipStream_t s);
+// `frame_words`: N 8-byte words of device memory
+hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *frame_words, hipStream_t s);
 hipError_t mmc_launch_sanitize(const Geom &g, const Arrays &a, hipStream_t s);
 hipError_t mmc_launch_fold_occ(const Geom &g, float *vx, const uint8_t *occ, size_t count, hipStream_t s);
 hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s);
+
+// Failure of an entry point that has no handle and must not allocate: `literal` (a string literal)
+// becomes what mmc_last_error(NULL) returns on this thread; returns `code`.
+int mmc_static_fail(int code, const char *literal);

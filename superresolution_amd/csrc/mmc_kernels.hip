@@ -15,6 +15,9 @@
 // atomics are issued in the iteration.
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <string.h>
+#include <mutex>
+#include "../../include/mmc_hip.h"
 #include "mmc_internal.h"
 
 #define FR(ptr, t) ((ptr) + (size_t)((t) + 1) * (size_t)g.N)
@@ -125,10 +128,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Sum NV per-thread values over the workgroup and add them to the slotted
-// double accumulators sums[first + i][slot].
+// Sum NV per-thread values over the workgroup: thread i < NV returns the sum of quantity i
+// (wave shuffle, then the waves' sums in wave order), every other thread returns 0.
 template <int NV>
-__device__ __forceinline__ void block_accumulate(float (&v)[NV], double *sums, int first) {
+__device__ __forceinline__ float block_sum(float (&v)[NV]) {
     __shared__ float red[NV][MMC_THREADS / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -137,10 +140,19 @@ __device__ __forceinline__ void block_accumulate(float (&v)[NV], double *sums, i
         if (lane == 0) red[i][wid] = s;
     }
     __syncthreads();
+    float s = 0.f;
     if (threadIdx.x < NV) {
-        float s = 0.f;
 #pragma unroll
         for (int k = 0; k < MMC_THREADS / 64; ++k) s += red[threadIdx.x][k];
+    }
+    return s;
+}
+
+// ... and add them to the slotted double accumulators sums[first + i][slot].
+template <int NV>
+__device__ __forceinline__ void block_accumulate(float (&v)[NV], double *sums, int first) {
+    const float s = block_sum<NV>(v);
+    if (threadIdx.x < NV) {
         int slot = (blockIdx.x + blockIdx.y * 7) & (MMC_SUM_SLOTS - 1);   // spread the atomics
         atomicAdd(&sums[(size_t)(first + threadIdx.x) * MMC_SUM_SLOTS + slot], (double)s);
     }
@@ -1358,8 +1370,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_fold_occ(float *vx, const uint8
 }
 
 // sums[6] += sum |W ub| over owned pairs, sums[7] += sum |G ub| over local
-// frames  (MultiframeMotionCoupling.m:431-437).
-__global__ __launch_bounds__(MMC_THREADS) void k_h_partials(Geom g, Arrays a) {
+// frames  (MultiframeMotionCoupling.m:431-437).  PER_BLOCK: the two sums of workgroup b go to
+// out[2b], out[2b+1] instead (no atomics; k_h_final adds them up in a fixed order).
+template <bool PER_BLOCK>
+__global__ __launch_bounds__(MMC_THREADS) void k_h_partials(Geom g, Arrays a, double *out) {
     const int t = blockIdx.y;
     const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
     float part[2] = {0.f, 0.f};
@@ -1378,7 +1392,28 @@ __global__ __launch_bounds__(MMC_THREADS) void k_h_partials(Geom g, Arrays a) {
             }
         }
     }
-    block_accumulate<2>(part, a.sums, 6);
+    if (PER_BLOCK) {
+        const float s = block_sum<2>(part);
+        if (threadIdx.x < 2) out[2 * ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) + threadIdx.x] = (double)s;
+    } else {
+        block_accumulate<2>(part, a.sums, 6);
+    }
+}
+
+// One workgroup: result[i] = sum over b < nblocks of part[2b + i], i = 0, 1, in an order that
+// depends on nblocks only (thread k takes b = k, k + 256, ...; then a binary tree in LDS).
+__global__ __launch_bounds__(MMC_THREADS) void k_h_final(const double *part, int nblocks, double *result) {
+    __shared__ double red[2][MMC_THREADS];
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += MMC_THREADS) { s0 += part[2 * (size_t)b]; s1 += part[2 * (size_t)b + 1]; }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int o = MMC_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) result[threadIdx.x] = red[threadIdx.x][0];
 }
 
 // --------------------------------------------------------------------------
@@ -1494,9 +1529,9 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
     return hipGetLastError();
 }
 
-hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *scratch, hipStream_t s) {
+hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *frame_words, hipStream_t s) {
     dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS), block(MMC_THREADS);
-    fx64 *tmp = static_cast<fx64 *>(scratch);
+    fx64 *tmp = static_cast<fx64 *>(frame_words);
     auto exists = [&](int q) { int gq = g.frame_begin + q; return q >= -1 && q <= g.L - 1 && gq >= 0 && gq <= g.nc_global - 2; };
     auto is_if = [&](int q) { return g.dir == 1 ? true : g.dir == 0 ? false : ((g.frame_begin + q) & 1) == 0; };
     for (int t = 0; t < g.L; ++t) {
@@ -1528,6 +1563,77 @@ hipError_t mmc_launch_fold_occ(const Geom &g, float *vx, const uint8_t *occ, siz
 
 hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s) {
     dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS, g.L), block(MMC_THREADS);
-    hipLaunchKernelGGL(k_h_partials, grid, block, 0, s, g, a);
+    hipLaunchKernelGGL(k_h_partials<false>, grid, block, 0, s, g, a, (double *)nullptr);
     return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------
+// h sums without a handle and without any allocation
+// --------------------------------------------------------------------------
+// Per-workgroup partial sums of mmc_h_partials_static live in this file-scope device array (every
+// GPU the library runs on holds its own copy until the process ends): two doubles per workgroup
+// of k_h_partials.  Host code never uses the array's name as an address; it asks the runtime for
+// the address on each device once (static_scratch_ptr) and passes that to the kernels.
+static __device__ __align__(256) double scratch[2 * (size_t)MMC_STATIC_MAX_BLOCKS];
+
+enum { MMC_STATIC_MAX_DEVICES = 64 };
+static std::mutex g_scratch_mutex;
+static double *g_scratch_ptr[MMC_STATIC_MAX_DEVICES];      // per device; null until first use there
+
+// Address of `scratch` on `device`, which must be the current device.
+static hipError_t static_scratch_ptr(int device, double **out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<double *>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
+extern "C" int mmc_h_partials_static(const float *d_u, const float *d_v, int Ny, int Nx, int nc,
+                                     int flow_direction, int device, void *stream, double *d_out) {
+    // everything that can be rejected is rejected before the first HIP call
+    if (!d_u || !d_out) return mmc_static_fail(MMC_ERR_INVALID_ARG, "mmc_h_partials_static: null frames or null output");
+    if (Ny <= 0 || Nx <= 0 || nc <= 0) return mmc_static_fail(MMC_ERR_INVALID_ARG, "mmc_h_partials_static: empty sequence");
+    if (nc > 1 && !d_v) return mmc_static_fail(MMC_ERR_INVALID_ARG, "mmc_h_partials_static: null flow");
+    if (flow_direction < 0 || flow_direction > 2) return mmc_static_fail(MMC_ERR_INVALID_ARG, "Invalid flow direction.");
+    if ((long long)Ny * Nx > (long long)INT_MAX / 4)
+        return mmc_static_fail(MMC_ERR_INVALID_ARG, "mmc_h_partials_static: frame too large for 32-bit pixel indexing");
+    if (device < 0 || device >= MMC_STATIC_MAX_DEVICES)
+        return mmc_static_fail(MMC_ERR_INVALID_ARG, "mmc_h_partials_static: device ordinal out of range");
+    const long long per_frame = ((long long)Ny * Nx + MMC_THREADS - 1) / MMC_THREADS;
+    if (per_frame * nc > (long long)MMC_STATIC_MAX_BLOCKS || nc > 65535)
+        return mmc_static_fail(MMC_ERR_INVALID_ARG,
+                               "mmc_h_partials_static: sequence exceeds the static workspace "
+                               "(ceil(Ny*Nx/256)*nc must not exceed MMC_STATIC_MAX_BLOCKS = 524288); use mmc_h_partials on a handle");
+    if (hipSetDevice(device) != hipSuccess) return mmc_static_fail(MMC_ERR_HIP, "mmc_h_partials_static: hipSetDevice failed");
+    double *part = nullptr;
+    if (static_scratch_ptr(device, &part) != hipSuccess)
+        return mmc_static_fail(MMC_ERR_HIP, "mmc_h_partials_static: hipGetSymbolAddress failed");
+
+    Geom g;
+    memset(&g, 0, sizeof(g));
+    g.Ny = Ny; g.Nx = Nx; g.N = Ny * Nx;
+    g.L = nc; g.frame_begin = 0; g.nc_global = nc;
+    g.dir = flow_direction;
+    Arrays a;
+    memset(&a, 0, sizeof(a));
+    // the kernels address frame t of a plane as base + (t+1)*N (slot 0 is a ghost frame that a
+    // whole sequence never touches), so the bases sit one frame before the caller's buffers
+    const size_t N = (size_t)g.N;
+    a.ub = const_cast<float *>(d_u) - N;
+    if (nc > 1) {
+        a.vx = const_cast<float *>(d_v) - N;
+        a.vy = const_cast<float *>(d_v) + (size_t)(nc - 1) * N - N;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)per_frame, (unsigned)nc), block(MMC_THREADS);
+    // every slot the final sum reads is written by the first kernel: nothing has to start at zero
+    hipLaunchKernelGGL(k_h_partials<true>, grid, block, 0, s, g, a, part);
+    hipLaunchKernelGGL(k_h_final, dim3(1), block, 0, s, part, (int)(per_frame * nc), d_out);
+    if (hipGetLastError() != hipSuccess) return mmc_static_fail(MMC_ERR_HIP, "mmc_h_partials_static: kernel launch failed");
+    return MMC_OK;
 }

@@ -89,3 +89,24 @@ def test_null_handle_is_rejected():
     assert lib.mmc_init(None) == -1
     assert lib.mmc_solve(None, 1, 0.0, 0, None, _capi.PROGRESS_CB(), None) == -1
     assert lib.mmc_destroy(None) == 0
+
+
+def test_static_entry_point_validates_before_touching_the_gpu():
+    """mmc_h_partials_static checks pointers and the size of its fixed workspace first, so a
+    rejection needs no device."""
+    lib = _capi.load_library()
+    bogus = C.c_void_p(256)
+    assert lib.mmc_h_partials_static(None, bogus, 8, 8, 2, 1, 0, None, bogus) == -1
+    assert "null" in lib.mmc_last_error(None).decode()
+    assert lib.mmc_h_partials_static(bogus, None, 8, 8, 2, 1, 0, None, bogus) == -1
+    assert lib.mmc_h_partials_static(bogus, bogus, 8, 8, 2, 5, 0, None, bogus) == -1
+    assert "Invalid flow direction" in lib.mmc_last_error(None).decode()
+    per_frame = (1080 * 1920 + 255) // 256
+    too_many = _capi.MMC_STATIC_MAX_BLOCKS // per_frame + 1
+    assert lib.mmc_h_partials_static(bogus, bogus, 1080, 1920, too_many, 1, 0, None, bogus) == -1
+    assert "static workspace" in lib.mmc_last_error(None).decode()
+    # a later mmc_create failure replaces the message
+    h = C.c_void_p()
+    p = _params(factor=0)
+    assert lib.mmc_create(C.byref(p), C.byref(h)) == -1
+    assert "Input must be > 0" in lib.mmc_last_error(None).decode()
