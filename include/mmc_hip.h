@@ -66,7 +66,7 @@ typedef struct mmc_params {
     int32_t frame_end;
     float alpha;               /* MultiframeMotionCoupling.m:207                       */
     float kappa;               /* :209; NaN = additive model (:515), 1 = model :500    */
-    float h;                   /* :437; <= 0: computed by mmc_init from this block     */
+    float h;                   /* :437; <= 0: computed (see mmc_init)                  */
     int32_t flow_direction;    /* mmc_flow_direction                                   */
     int32_t sampling;          /* mmc_sampling                                         */
     int32_t device;            /* HIP device ordinal                                   */
@@ -172,7 +172,10 @@ int mmc_num_state_frames(const mmc_handle *h);
 int mmc_set_fixed_frame(mmc_handle *h, const float *u0, const float *w0);
 
 /* Out-of-range / occlusion masks, column sums of the warp, tile source boxes,
- * step sizes and (when params.h <= 0) h from this block's own sums.
+ * step sizes and, for a block without neighbours and params.h <= 0, h from its
+ * own sums.  A block of a sharded sequence holds only part of those sums: with
+ * params.h <= 0 its h stays unset, and the sweeps return MMC_ERR_STATE, until
+ * mmc_set_h has been called with the ratio of the all-reduced mmc_h_partials.
  * Replaces the one-off part of init_u_prost, MultiframeMotionCoupling.m:389-437. */
 int mmc_init(mmc_handle *h);
 
@@ -262,6 +265,11 @@ int mmc_debug_apply_KT(mmc_handle *h, const float *p, const float *g1, const flo
  * (N*L each, one per pixel group). */
 int mmc_debug_steps(mmc_handle *h, float *tau_u, float *tau_w,
                     float *sigma_p, float *sigma_g1, float *sigma_g2);
+/* tau as the update sweep itself derives it: there the column sums of the motion-coupling
+ * operator come out of the tile scatter of the tap weights plus two identity bits per pixel,
+ * not from the plane that mmc_init wrote (which mmc_debug_steps reads).  Both must agree
+ * bit for bit. */
+int mmc_debug_steps_update(mmc_handle *h, float *tau_u, float *tau_w);
 
 #ifdef __cplusplus
 }

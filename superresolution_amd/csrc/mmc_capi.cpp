@@ -683,8 +683,10 @@ extern "C" int mmc_init(mmc_handle *h) {
     }
     HIPCHK(h, mmc_launch_init_warp(g, a, h->scratch, h->stream));
     HIPCHK(h, mmc_launch_sanitize(g, a, h->stream));
-    if (!h->have_h) {
-        // MultiframeMotionCoupling.m:431-437, from this block's own sums
+    if (!h->have_h && !h->has_prev && !h->has_next) {
+        // MultiframeMotionCoupling.m:431-437.  A block with neighbours holds only part of the two
+        // sums (a trailing one-frame block owns no pair at all): there h stays unset until the
+        // caller has added mmc_h_partials up over all blocks and called mmc_set_h.
         double s[2];
         if ((rc = mmc_h_partials(h, s))) return rc;
         if (g.nc_global == 1) {
@@ -705,6 +707,8 @@ extern "C" int mmc_init(mmc_handle *h) {
 
 static int check_range(mmc_handle *h, int t0, int t1) {
     if (!h->inited) return fail(h, MMC_ERR_STATE, "No initialization found, run mmc_init first.");
+    if (!h->have_h)
+        return fail(h, MMC_ERR_STATE, "sweep: h is not set; add mmc_h_partials up over all blocks of the sequence and call mmc_set_h");
     if (t0 < 0 || t1 > h->L || t1 < t0) return fail(h, MMC_ERR_INVALID_ARG, "sweep: frame range outside the block");
     return MMC_OK;
 }
@@ -1051,15 +1055,27 @@ extern "C" int mmc_debug_apply_KT(mmc_handle *h, const float *p, const float *g1
     return MMC_OK;
 }
 
+static int debug_steps(mmc_handle *h, int primal_mode, float *tau_u, float *tau_w,
+                       float *sigma_p, float *sigma_g1, float *sigma_g2);
+
 extern "C" int mmc_debug_steps(mmc_handle *h, float *tau_u, float *tau_w,
                                float *sigma_p, float *sigma_g1, float *sigma_g2) {
+    return debug_steps(h, MODE_STEPS, tau_u, tau_w, sigma_p, sigma_g1, sigma_g2);
+}
+
+extern "C" int mmc_debug_steps_update(mmc_handle *h, float *tau_u, float *tau_w) {
+    return debug_steps(h, MODE_STEPS_UPD, tau_u, tau_w, nullptr, nullptr, nullptr);
+}
+
+static int debug_steps(mmc_handle *h, int primal_mode, float *tau_u, float *tau_w,
+                       float *sigma_p, float *sigma_g1, float *sigma_g2) {
     REQUIRE_HANDLE(h);
     if (!h->inited) return fail(h, MMC_ERR_STATE, "No initialization found, run mmc_init first.");
     int rc = use_device(h); if (rc) return rc;
     const Geom &g = h->g;
     Arrays &a = h->a;
     const size_t B = (size_t)h->L * g.N * sizeof(float), o = (size_t)g.N;
-    HIPCHK(h, mmc_launch_primal(g, a, 0, h->L, MODE_STEPS, false, h->stream));
+    HIPCHK(h, mmc_launch_primal(g, a, 0, h->L, primal_mode, false, h->stream));
     HIPCHK(h, mmc_launch_dual(g, a, 0, h->L, MODE_STEPS, false, h->stream));
     if (tau_u) HIPCHK(h, hipMemcpyAsync(tau_u, a.ub + o, B, hipMemcpyDeviceToHost, h->stream));
     if (tau_w && g.model == MODEL_IC) HIPCHK(h, hipMemcpyAsync(tau_w, a.wb + o, B, hipMemcpyDeviceToHost, h->stream));

@@ -6,7 +6,9 @@
 #include <stdint.h>
 
 enum { MODEL_IC = 0, MODEL_K1 = 1, MODEL_ADD = 2 };
-enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3 };
+// MODE_STEPS_UPD (primal sweep only): the step sizes exactly as MODE_UPDATE derives them (column sums of W
+// from the scatter and the identity bits), where MODE_STEPS reads the cW plane written by mmc_init.
+enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3, MODE_STEPS_UPD = 4 };
 
 // One workgroup of 256 threads owns a TILE_R x TILE_C pixel tile of one frame.
 // Rows are the contiguous axis (column-major frames), so one 64-lane wave

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
     extern __shared__ __align__(16) float lds[];
     // In the update sweep the tap weights are scattered along with the duals, which yields the
     // scattered part of cW without reading the cW plane (4 bytes per pixel less).
-    constexpr bool CWS = MMC_CW_SCATTER && MODE == MODE_UPDATE;
+    constexpr bool CWS = MMC_CW_SCATTER && (MODE == MODE_UPDATE || MODE == MODE_STEPS_UPD);
     fx64 *acc1 = reinterpret_cast<fx64 *>(lds);
     fx64 *acc2 = acc1 + TILE_R * TILE_C;
     fx64 *acc3 = acc2 + TILE_R * TILE_C;
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             }
         };
         compute_tau();
-        if (MODE == MODE_STEPS) {
+        if (MODE == MODE_STEPS || MODE == MODE_STEPS_UPD) {
             st4(ub, tau_u);
             if (MODEL == MODEL_IC) st4(wb, tau_w);
         } else {
@@ -1424,7 +1424,8 @@ template <int MODEL>
 static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     dim3 grid(g.ntiles, nf), block(MMC_THREADS);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal<MODEL, MODE_RAW, false>), grid, block, 0, s, g, a, t0);
-    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal<MODEL, MODE_STEPS, false>), grid, block, 0, s, g, a, t0);
+    else if (mode == MODE_STEPS || mode == MODE_STEPS_UPD)      // the scalar kernel always reads the cW plane
+        hipLaunchKernelGGL((k_primal<MODEL, MODE_STEPS, false>), grid, block, 0, s, g, a, t0);
     else if (reduce) hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, true>), grid, block, 0, s, g, a, t0);
     else hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
 }
@@ -1443,6 +1444,7 @@ static void launch_primal4_m(const Geom &g0, const Arrays &a, int t0, int nf, in
     const size_t lds = (size_t)(6 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_STEPS_UPD) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS_UPD, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0, nf);
     else hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0, nf);
 }

@@ -191,9 +191,18 @@ class MultiframeMotionCoupling(object):
         s.set_blur(self.k)                                           # :373-375
         s.set_flow(v, self._occ)                                     # :389-412
         u_up = upsample_sequence(self._imageSequenceSmall, int(self.factor))   # :415-419
-        u0 = u_up if self._u is None else self._u
-        w0 = u_up if self._w is None else self._w
-        s.set_state(u0, w0)
+        # h is always taken from the bicubic estimate (:432-437), whatever the start point is (:446-456)
+        s.set_state(u_up, u_up)
+        if nc > 1:
+            warpPix, gradPix = s.h_partials()
+            if not (warpPix > 0 and gradPix > 0):
+                s.close()
+                raise MMCError(-1, "warp or gradient energy of the bicubic estimate is zero, h is undefined")
+            s.h = warpPix / gradPix
+        else:
+            s.h = 1.0
+        if self._u is not None or self._w is not None:
+            s.set_state(u_up if self._u is None else self._u, u_up if self._w is None else self._w)
         if self._u0_frame is not None:                               # :535-572
             if np.isnan(self.kappa) or self.kappa == 1:
                 raise MMCError(-1, "u0_frame/w0_frame need the infimal-convolution model (kappa not 1, not NaN)")

@@ -65,6 +65,21 @@ def halo_tensors(solver):
             for name in ("send_prev", "recv_next", "send_next", "recv_prev")}
 
 
+def require_torch_stream(solver):
+    """The exchange is ordered against torch's current stream: the RCCL send/recv kernels (or the
+    staged copies) wait for work queued there and `wait()` makes that stream wait for them.  The
+    sweeps must therefore be queued on the same stream.  A FrameBlockSolver created with
+    stream=None, or with the default stream (handle 0), runs on a private stream of the library,
+    and the frames would be sent and overwritten while the sweeps are still running."""
+    import torch
+    lib_stream = solver.params.stream or 0
+    cur = torch.cuda.current_stream(solver.params.device).cuda_stream
+    if lib_stream == 0 or lib_stream != cur:
+        raise RuntimeError("the FrameBlockSolver must be created with stream=torch.cuda.current_stream().cuda_stream of a "
+                           "non-default stream, and that stream must be current during solve_sharded "
+                           "(library stream %#x, torch current stream %#x)" % (lib_stream, cur))
+
+
 class HaloExchanger(object):
     """Posts the two per-iteration exchanges of one block as batched isend/irecv.
 
@@ -84,6 +99,7 @@ class HaloExchanger(object):
         self.next = rank + 1 if rank < world - 1 else None
         self.group = group
         on_device = any(t is not None and t.is_cuda for ts in tensors.values() for t in ts)
+        self.on_device = on_device
         self.staged = on_device and dist.get_backend(group) != "nccl"
         self.host = {}
         if self.staged:
@@ -161,6 +177,8 @@ def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=N
     start at zero on both sides, matching the zero start of the duals.
     """
     L = engine.L
+    if getattr(exchanger, "on_device", False) and hasattr(engine, "params"):
+        require_torch_stream(engine)
     has_prev = exchanger.prev is not None
     has_next = exchanger.next is not None
     if check_every <= 0:

@@ -278,3 +278,11 @@ class FrameBlockSolver(object):
         s2 = np.empty(N * L, np.float32)
         self._check(self._lib.mmc_debug_steps(self._h, fptr(tu), fptr(tw), fptr(sp), fptr(s1), fptr(s2)))
         return tu, tw, sp, s1, s2
+
+    def debug_steps_update(self):
+        """tau_u, tau_w as the update sweep derives them (see mmc_debug_steps_update)."""
+        N, L = self.Ny * self.Nx, self.L
+        tu = np.empty(N * L, np.float32)
+        tw = np.empty(N * L, np.float32) if self.has_w else None
+        self._check(self._lib.mmc_debug_steps_update(self._h, fptr(tu), fptr(tw)))
+        return tu, tw

@@ -15,6 +15,8 @@ UNPINNED with respect to the real prost/flexBox binaries.
                         anti-aliased, clipped), and Lucas-Kanade flows estimated
                         on the LR frames and upscaled x4 like
                         MultiframeMotionCoupling.m:958-959.
+  tube3_full.npz        the same for the whole 600x600 frames (150x150 LR): the size
+                        testfile.m:22-31 runs at.
 Run from the repository root:  python tests/golden/make_golden.py [/root/reference]
 """
 import os
@@ -76,11 +78,10 @@ def lucas_kanade(a, b, win=7, iters=3):
     return dy, dx
 
 
-def tube3_crop(reference_root):
+def tube3_crop(reference_root, sl=slice(172, 428), out_name="tube3_crop.npz"):
     from PIL import Image
     folder = os.path.join(reference_root, "data", "video_scenes", "tube3")
     names = sorted(n for n in os.listdir(folder) if n.lower().endswith(".png"))[:3]
-    sl = slice(172, 428)
     truth = []
     for n in names:
         rgb = np.asarray(Image.open(os.path.join(folder, n)).convert("RGB"), dtype=np.float64) / 255.0
@@ -92,12 +93,12 @@ def tube3_crop(reference_root):
     # helpers/LoadImSequence.m:45-46, :61-62
     lr = np.clip(np.stack([orc.imresize(truth[:, :, i], 0.25, "bicubic", True) for i in range(3)], axis=2), 0, 1)
     # backward convention: u_t(x) ~ u_{t+1}(x + v_t(x))
-    flows = np.zeros((64, 64, 2, 2))
+    flows = np.zeros(lr.shape[:2] + (2, 2))
     for i in range(2):
         dy, dx = lucas_kanade(lr[:, :, i], lr[:, :, i + 1])
         flows[:, :, i, 0] = dx          # component 1: along columns
         flows[:, :, i, 1] = dy          # component 2: along rows
-    np.savez_compressed(os.path.join(HERE, "tube3_crop.npz"), truth_u8=truth8,
+    np.savez_compressed(os.path.join(HERE, out_name), truth_u8=truth8,
                         lr=lr.astype(np.float32), flow_lr=flows.astype(np.float16), frames=np.array(names))
 
 
@@ -106,6 +107,7 @@ if __name__ == "__main__":
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     if os.path.isdir(ref):
         tube3_crop(ref)
+        tube3_crop(ref, slice(0, 600), "tube3_full.npz")      # testfile.m:22-31 at its real size
     else:
         print("reference checkout not found; tube3_crop.npz not regenerated")
     for n in sorted(os.listdir(HERE)):

@@ -92,6 +92,45 @@ def test_block_solve_entry_point_refuses_blocks_with_neighbours():
         b.close()
 
 
+def test_block_with_neighbours_needs_h_before_sweeping():
+    """A block of a sharded sequence only holds part of the sums behind h (a trailing one-frame
+    block holds no pair at all): mmc_init leaves h unset there and the sweeps refuse to run until
+    the all-reduced value has been set."""
+    from superresolution_amd import MMCError
+    f, v, occ = make_case(3, 8, 8, 3)
+    P = orc.build_problem(f, v, k=KBLUR)
+    blocks = _make_blocks(f, v, None, P, 0.25, "backward", [(0, 2), (2, 3)])
+    last = blocks[1]
+    assert last.h_partials()[0] == 0.0                      # no pair owned
+    with pytest.raises(MMCError, match="h is not set"):
+        last.sweep_primal(0, 1)
+    parts = np.array([b.h_partials() for b in blocks]).sum(axis=0)
+    for b in blocks:
+        b.h = parts[0] / parts[1]
+    last.sweep_primal(0, 1)
+    last.sync()
+    for b in blocks:
+        b.close()
+
+
+def test_sharded_loop_refuses_a_private_library_stream():
+    """solve_sharded orders the exchange against torch's current stream; a solver on the library's
+    own stream would race with it."""
+    import torch
+    from superresolution_amd import sharding
+    f, v, occ = make_case(3, 8, 8, 4)
+    P = orc.build_problem(f, v, k=KBLUR)
+    blocks = _make_blocks(f, v, None, P, 0.25, "backward", [(0, 2), (2, 4)])      # stream=None
+
+    class FakeExchanger(object):
+        on_device, prev, next = True, None, 1
+
+    with pytest.raises(RuntimeError, match="current_stream"):
+        sharding.solve_sharded(blocks[0], FakeExchanger(), 1)
+    for b in blocks:
+        b.close()
+
+
 def test_blocks_with_a_generic_sampler():
     """Frame blocks with a sampler given by taps (bicubic with antialiasing): the sparse border rows
     and their per-frame correction planes are indexed by local frames in every block."""

@@ -49,6 +49,28 @@ def test_tube3_parity_and_psnr():
     m.close()
 
 
+def test_h_comes_from_the_bicubic_estimate_on_reinit():
+    """MultiframeMotionCoupling.m:432-437 computes h from u_up whatever obj.u holds (:446-450):
+    init() after run() must give the same h, and start from the previous result."""
+    from superresolution_amd.mmc import MultiframeMotionCoupling
+    f, v, _ = make_case(21, 8, 8, 3)
+    P = orc.build_problem(f, v, k=KBLUR)
+    m = MultiframeMotionCoupling(f, flowField=v, verbose=0)
+    m.k = KBLUR
+    m.comp_mode = "fast"
+    m.init()
+    h0 = m.h
+    assert abs(h0 - P.h) < 1e-5 * P.h
+    m._opts["max_iters"], m._opts["tol"] = 40, 0.0
+    m.run()
+    u1 = m.result1.copy()
+    m.init()
+    assert m.h == h0
+    u_start, _ = m._solver.get_state()
+    assert np.array_equal(u_start, u1.astype(np.float32))
+    m.close()
+
+
 def test_colour_input_and_presets():
     """4-D RGB input goes through Y of rgb2ycbcr (:110-119) and comes back as RGB (:1022-1046);
     'fastest' switches to the additive model (:283-290) and stops on the 1e-4 tolerance."""

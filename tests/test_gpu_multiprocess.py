@@ -50,7 +50,9 @@ def _worker(rank, world, port, nc, kappa, direction, iters, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nc,kappa,direction", [(2, 5, 0.25, "backward"), (3, 6, float("nan"), "forward-backward")])
+# (3, 3, ...): one frame per rank; the last rank owns no flow pair, so its share of sum|W u| is zero
+@pytest.mark.parametrize("world,nc,kappa,direction", [(2, 5, 0.25, "backward"), (3, 6, float("nan"), "forward-backward"),
+                                                      (3, 3, 0.25, "backward")])
 def test_two_processes_one_gpu(tmp_path, world, nc, kappa, direction):
     import torch.multiprocessing as mp
     iters = 30
