@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """Throughput of the MMC super-resolution PDHG solve on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--total-frames T] [--lr ny nx]
 
 A step is one PDHG iteration (primal sweep + dual sweep) over this rank's frame
-block.  Workload: synthetic 1080p sequence, 30 HR frames of 1080x1920 per GPU
-(LR 270x480, zoom 4), infimal-convolution model (kappa 0.25), alpha 0.01,
-backward flow, 7x7 Gaussian blur + 4x4 block mean; with N GPUs the sequence has
-30*N frames, block-sharded, boundary frames exchanged every sweep (weak
-scaling).  Inputs are resident in HBM before the timed region.  Rank 0 prints
-one JSON line.
+block.  Workload: synthetic 1080p sequence, HR frames of 1080x1920 (LR 270x480,
+zoom 4), infimal-convolution model (kappa 0.25), alpha 0.01, backward flow, 7x7
+Gaussian blur + 4x4 block mean.  Default (weak scaling): 30 frames per GPU, the
+sequence has 30*N frames.  --total-frames T fixes the sequence (strong scaling):
+240 for the long 1080p sequence, `--lr 540 960 --total-frames 120` for the 4K
+one; frames are block-sharded, boundary frames exchanged every sweep.  Inputs
+are resident in HBM before the timed region.  Rank 0 prints one JSON line.
+
+With --gpus N > 1 and no launcher environment, this process starts the N ranks
+itself (python -m torch.distributed.run, one process per GPU, 127.0.0.1) before
+it touches any GPU, relays their output and exits with their status.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +37,16 @@ BYTES_PRIMAL = {"ic": 14.0625 * 4, "single": 8.0625 * 4}
 BYTES_DUAL = {"ic": 16.1875 * 4, "single": 9.1875 * 4}
 BYTES_ITER = {"ic": 121.0, "single": 69.0}
 HBM_PEAK = 8.0e12
+PMC_SUMMARIES = ("r2_pmc_hbm_bytes.json", "r1_pmc_hbm_bytes.json")
+
+
+def log(msg):
+    """Progress on stderr (unbuffered): a stall under a profiler names its phase."""
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.perf_counter()
 
 
 def parse():
@@ -38,9 +55,18 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames-per-gpu", type=int, default=30)
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="fixed sequence length, block-sharded over the GPUs (strong scaling); 0: frames-per-gpu * gpus")
     ap.add_argument("--lr", type=int, nargs=2, default=[270, 480], metavar=("ny", "nx"))
     ap.add_argument("--kappa", type=float, default=0.25)
+    ap.add_argument("--flow", default="rigid", choices=["rigid", "smooth", "outliers"],
+                    help="flow field of the headline run (see synthetic.perturb_flows)")
+    ap.add_argument("--extra-flows", default="smooth,outliers",
+                    help="comma list of further flow kinds timed after the headline run at N=1 (extra keys only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="render the synthetic inputs with torch on the CPU, so that this process launches no "
+                         "kernels but the library's (for hardware-counter runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional rehearsal: ranks share the visible GPUs (use with --backend gloo)")
@@ -48,10 +74,25 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(args):
+    """Start the ranks of an N-GPU run from a plain `python bench.py --gpus N`.  Nothing in this
+    process has touched a GPU; the children are fresh processes."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(args, budget_s):
-    """The oracle's PDHG iteration timed on the host cores: a bounded sample of the same
-    workload (first 6 frames, 544x960 HR) with the C/OpenMP restatement, or, if that cannot
-    be built, a smaller crop with the scipy.sparse restatement on one core."""
+    """The oracle's PDHG iteration timed on the host cores, on a bounded sample: the first frames
+    of the workload at full frame size with the C/OpenMP restatement (explicit sparse rows for W'
+    and D*B, matrix-free gradient), plus the reference's own quick-start size (600x600x3) in
+    full; or, if the C library cannot be built, a small crop with the scipy.sparse restatement."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from superresolution_amd import synthetic
     try:
@@ -59,16 +100,27 @@ def cpu_baseline(args, budget_s):
         have_c = oc.available()
     except Exception:
         have_c = False
-    ny, nx, nc = (136, 240, 6) if have_c else (64, 96, 3)
-    blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
     k = synthetic.gaussian_kernel()
+    host_cpus = os.cpu_count()
     if have_c:
-        res = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, budget_s=budget_s)
-        return {"value": res["mpx_iter_per_s"], "unit": "HR Mpixel*PDHG-iters/s", "cores": res["threads"],
-                "kind": "port",
-                "sample": "%dx%dx%d HR crop of the workload, %d iterations, C/OpenMP matrix-free restatement (oracle/mmc_oracle_c.c)"
-                          % (4 * ny, 4 * nx, nc, res["iterations"])}
+        ny, nx = args.lr
+        nc = 4
+        blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
+        res = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, budget_s=0.7 * budget_s)
+        out = {"value": res["mpx_iter_per_s"], "unit": "HR Mpixel*PDHG-iters/s", "cores": res["threads"],
+               "kind": "port", "host_cpus": host_cpus,
+               "sample": "first %d frames of the workload at full size (%dx%dx%d HR), %d iterations, C/OpenMP restatement "
+                         "with explicit sparse rows for the warp adjoint and D*B (oracle/mmc_oracle_c.c); "
+                         "loop time only, operator set-up excluded"
+                         % (nc, 4 * ny, 4 * nx, nc, res["iterations"])}
+        blk = synthetic.make_block(150, 150, 3, 0, 3, device="cpu")
+        r1 = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, budget_s=0.3 * budget_s, max_iters=800)
+        out["quickstart_600x600x3"] = {"value": r1["mpx_iter_per_s"], "iterations": r1["iterations"],
+                                       "seconds_per_800_iterations": 800 * 1.08 / r1["mpx_iter_per_s"]}
+        return out
     import mmc_oracle as orc
+    ny, nx, nc = 64, 96, 3
+    blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
     P = orc.build_problem(blk["f"], blk["v"], kappa=args.kappa, k=k)
     x, y, _ = orc.pdhg(P, 2)
     t0 = time.perf_counter()
@@ -78,6 +130,7 @@ def cpu_baseline(args, budget_s):
         iters += 10
     dt = time.perf_counter() - t0
     return {"value": P.M * iters / dt / 1e6, "unit": "HR Mpixel*PDHG-iters/s", "cores": 1, "kind": "port",
+            "host_cpus": host_cpus,
             "sample": "%dx%dx%d HR crop of the workload, %d iterations, scipy.sparse restatement (oracle/mmc_oracle.py)"
                       % (4 * ny, 4 * nx, nc, iters)}
 
@@ -85,38 +138,39 @@ def cpu_baseline(args, budget_s):
 def measured_traffic(kernel, model, L, Ny, Nx):
     """HBM bytes per launch of `kernel` from the committed hardware-counter summary
     (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes over this same workload;
-    FETCH_SIZE doubled as gfx950 needs).  None when the summary is for another workload."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_bytes.json")
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-    except (OSError, ValueError):
-        return None
-    wl = d.get("workload", {})
-    if wl.get("frames") != L or wl.get("hr") != [Ny, Nx] or wl.get("model") != model:
-        return None
-    for name, v in d.get("kernels", {}).items():
-        if name.startswith(kernel + "<") and ", false," in name:
-            return v["hbm_bytes_per_launch"]
-    return None
+    FETCH_SIZE doubled as gfx950 needs).  None when no summary is for this workload."""
+    for fname in PMC_SUMMARIES:
+        path = os.path.join(ROOT, "profiles", fname)
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        wl = d.get("workload", {})
+        if wl.get("frames") != L or wl.get("hr") != [Ny, Nx] or wl.get("model") != model:
+            continue
+        for name, v in d.get("kernels", {}).items():
+            if name.startswith(kernel + "<") and ", false," in name:
+                return v["hbm_bytes_per_launch"], "profiles/" + fname
+    return None, None
 
 
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
     import torch
     from superresolution_amd import synthetic
     from superresolution_amd.imresize import upsample_sequence
     from superresolution_amd.solver import FrameBlockSolver
     from superresolution_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible")
     if args.share_gpu:
@@ -124,6 +178,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
@@ -133,16 +188,26 @@ def main():
         # the library queues on torch's current stream so that torch orders kernels and transfers;
         # a stream of our own, because the default stream's handle is 0 (= "library, make your own")
         torch.cuda.set_stream(torch.cuda.Stream())
+        one = torch.ones(1, dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     ny, nx = args.lr
-    L = args.frames_per_gpu
-    nc = L * world
-    begin, end = rank * L, (rank + 1) * L
     factor = 4
     Ny, Nx = ny * factor, nx * factor
+    if args.total_frames > 0:
+        nc = args.total_frames
+        scaling = "strong"
+    else:
+        nc = args.frames_per_gpu * world
+        scaling = "weak"
+    begin, end = sharding.partition_frames(nc, world)[rank]
+    L = end - begin
     model = "ic" if not (np.isnan(args.kappa) or args.kappa == 1) else "single"
+    in_dev = "cpu" if args.host_inputs else dev
 
-    blk = synthetic.make_block(ny, nx, nc, begin, end, factor=factor, device=dev)
+    log("rank %d: rendering frames [%d, %d) of %d on %s" % (rank, begin, end, nc, in_dev))
+    blk = synthetic.make_block(ny, nx, nc, begin, end, factor=factor, device=in_dev, flow_kind=args.flow)
     u_up = upsample_sequence(blk["f_state"], factor).astype(np.float32)
     stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
     s = FrameBlockSolver(ny, nx, factor, nc, begin, end, alpha=0.01, kappa=args.kappa, h=0.0,
@@ -151,33 +216,56 @@ def main():
     s.set_blur(synthetic.gaussian_kernel())
     s.set_flow(blk["v"])
     s.set_state(u_up, u_up)
-    del blk, u_up
+    del blk
+    log("rank %d: mmc_init" % rank)
     s.init()
 
     M_local = Ny * Nx * L
+    M_total = Ny * Nx * nc
     prof = None
+    extra = {}
     if world == 1:
+        log("warm-up, %d iterations" % args.warmup)
         s.solve(args.warmup, 0.0, 0)
         s.set_profiling(True)
         torch.cuda.synchronize()
+        log("timed region, %d iterations" % args.steps)
         t0 = time.perf_counter()
         st = s.solve(args.steps, 0.0, 0)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         prof = s.get_profile()
+        log("timed region done: %.3f ms per iteration" % (wall / args.steps * 1e3))
+        s.set_profiling(False)
+        # the same sweeps on irregular flow fields (extra keys; the headline stays the line above)
+        for kind in [k for k in args.extra_flows.split(",") if k and k != args.flow]:
+            log("flow kind '%s'" % kind)
+            blk2 = synthetic.make_block(ny, nx, nc, begin, end, factor=factor, device=in_dev, flow_kind=kind)
+            s.set_flow(blk2["v"])
+            del blk2
+            s.set_state(u_up, u_up)
+            s.init()
+            s.solve(max(args.warmup // 2, 2), 0.0, 0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            s.solve(args.steps, 0.0, 0)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / args.steps * 1e3
+            extra[kind] = {"ms_per_step": ms, "value": M_total / ms / 1e3, "vs_headline": (wall / args.steps * 1e3) / ms}
     else:
-        s.h = sharding.sharded_h(s, dev)
+        s.h = sharding.sharded_h(s, dev if args.backend == "nccl" else None)
         ex = sharding.HaloExchanger(sharding.halo_tensors(s), rank, world)
-        sharding.solve_sharded(s, ex, args.warmup, 0.0, 0, dev)
+        red_dev = dev if args.backend == "nccl" else None
+        sharding.solve_sharded(s, ex, args.warmup, 0.0, 0, red_dev)
         s.set_profiling(True)
-        dist.barrier()
         torch.cuda.synchronize()
+        dist.barrier()
         t0 = time.perf_counter()
-        st = sharding.solve_sharded(s, ex, args.steps, 0.0, 0, dev)
+        st = sharding.solve_sharded(s, ex, args.steps, 0.0, 0, red_dev)
         torch.cuda.synchronize()
         dist.barrier()
         wall = time.perf_counter() - t0
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
         # this rank's sweeps, HIP events on the library's stream; a sweep is two launches when the
@@ -192,7 +280,6 @@ def main():
     assert st["iterations"] == args.steps
 
     if rank == 0:
-        M_total = M_local * world
         value = M_total * args.steps / wall / 1e6
         out = {
             "metric": "HR Mpixel*PDHG-iters/s per node",
@@ -200,17 +287,21 @@ def main():
             "unit": "HR Mpixel*PDHG-iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic 1080p-style sequence, %d HR frames of %dx%d per GPU (LR %dx%d, zoom 4), "
-                                   "%s model kappa=%g, alpha=0.01, backward flow, gaussian(7,sqrt(0.6)) blur + 4x4 mean"
-                                   % (L, Ny, Nx, ny, nx, "infimal-convolution" if model == "ic" else "single-primal", args.kappa),
-                       "frames_total": nc, "hr_pixels_total": M_total, "parallelism": "frame-block x%d" % world},
+            "config": {"workload": "synthetic sequence, %d HR frames of %dx%d (LR %dx%d, zoom 4), %d on rank 0, "
+                                   "%s model kappa=%g, alpha=0.01, backward flow (%s), gaussian(7,sqrt(0.6)) blur + 4x4 mean"
+                                   % (nc, Ny, Nx, ny, nx, L, "infimal-convolution" if model == "ic" else "single-primal",
+                                      args.kappa, args.flow),
+                       "frames_total": nc, "hr_pixels_total": M_total, "parallelism": "frame-block x%d" % world,
+                       "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None},
             "wall_s_per_sr_frame_at_7500_iters": wall / args.steps * 7500 / nc,
             "iteration_roofline": {"bytes_per_px_iter": BYTES_ITER[model],
                                    "achieved_GBps_per_gpu": BYTES_ITER[model] * M_total * args.steps / wall / world / 1e9,
                                    "frac_of_8TBps": BYTES_ITER[model] * M_total * args.steps / wall / world / HBM_PEAK},
         }
+        if extra:
+            out["other_flows"] = extra
         if prof is not None and prof["iterations"] > 0:
             # the dual sweep is one fused kernel (k_dual4); its second slot only times the event gap
             kernels = {"k_primal4": (prof["primal_ms"], BYTES_PRIMAL[model]),
@@ -218,19 +309,22 @@ def main():
             name = max(kernels, key=lambda n: kernels[n][0])
             ms, bpp = kernels[name]
             achieved = bpp * M_local / (ms * 1e-3) / 1e9
+            traffic, source = measured_traffic(name, model, L, Ny, Nx)
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK / 1e9,
                                "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9),
-                               "traffic": measured_traffic(name, model, L, Ny, Nx),
-                               "traffic_source": "profiles/r1_pmc_hbm_bytes.json (rocprofv3 --pmc, bytes per launch)",
+                               "traffic": traffic,
+                               "traffic_source": None if source is None else source + " (rocprofv3 --pmc, bytes per launch)",
                                "algorithmic_bytes_per_launch": bpp * M_local, "avg_launch_ms": ms,
                                "launches_timed": prof["iterations"],
                                "all_kernels_ms": {k: v[0] for k, v in kernels.items()}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
+            log("cpu baseline")
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             except Exception as e:      # the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
+        sys.stdout.flush()
     s.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -70,7 +70,7 @@ def solve(f_lr, v, u0, w0, iters, k=None, factor=4, alpha=0.01, kappa=0.25, flow
     return u, w, info
 
 
-def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0):
+def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0, max_iters=2000):
     """Throughput of the C restatement: iterations sized to roughly fill `budget_s`."""
     import sys
     sys.path.insert(0, HERE)
@@ -81,7 +81,7 @@ def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0):
     M = 16 * ny * nx * nc
     _, _, probe = solve(f_lr, v, u_up, u_up, 3, k=k, kappa=kappa, threads=threads)
     per_it = max(probe["loop_seconds"] / 3, 1e-6)
-    iters = int(min(max(budget_s / per_it, 5), 2000))
+    iters = int(min(max(budget_s / per_it, 5), max_iters))
     t0 = time.perf_counter()
     _, _, info = solve(f_lr, v, u_up, u_up, iters, k=k, kappa=kappa, threads=threads)
     return {"mpx_iter_per_s": M * iters / info["loop_seconds"] / 1e6, "iterations": iters,

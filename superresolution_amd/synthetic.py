@@ -110,8 +110,42 @@ def flows_backward(masks):
     return v
 
 
+FLOW_KINDS = ("rigid", "smooth", "outliers")
+
+
+def perturb_flows(v, pair_ids, kind, seed=777):
+    """Irregular variants of the analytic flow, for throughput studies (the data term still comes
+    from the rigid scene, so these flows do not describe it -- the sweeps do the same work).
+      'smooth'   adds a low-frequency random field of about 3 px amplitude (bicubic blow-up of a
+                 coarse 9x16 grid of N(0, 1.5) values), different for every pair;
+      'outliers' additionally replaces 0.1 % of the vectors by uniform ones in [-200, 200]^2,
+                 as an estimator does at occlusions.
+    A pure function of (seed, global pair index): blocks of one sequence agree on shared pairs."""
+    if kind == "rigid":
+        return v
+    if kind not in FLOW_KINDS:
+        raise ValueError("flow kind must be one of %s" % (FLOW_KINDS,))
+    Ny, Nx = v.shape[:2]
+    out = v.clone()
+    for i, q in enumerate(pair_ids):
+        rng = np.random.default_rng([seed, int(q)])
+        coarse = torch.as_tensor(rng.normal(0.0, 1.5, (1, 2, 9, 16)), dtype=torch.float32, device=v.device)
+        field = torch.nn.functional.interpolate(coarse, size=(Ny, Nx), mode="bicubic", align_corners=True)[0]
+        out[:, :, i, 0] += field[0]
+        out[:, :, i, 1] += field[1]
+        if kind == "outliers":
+            cnt = max(int(round(1e-3 * Ny * Nx)), 1)
+            idx = torch.as_tensor(rng.choice(Ny * Nx, size=cnt, replace=False), device=v.device)
+            vec = torch.as_tensor(rng.uniform(-200.0, 200.0, (cnt, 2)), dtype=torch.float32, device=v.device)
+            for comp in range(2):
+                plane = out[:, :, i, comp].reshape(-1)          # a copy (the slice is not contiguous)
+                plane[idx] = vec[:, comp]
+                out[:, :, i, comp] = plane.reshape(Ny, Nx)
+    return out
+
+
 def make_block(ny, nx, nc_global, begin, end, factor=4, seed=1234, noise_seed=4321, device="cpu",
-               with_truth=False):
+               with_truth=False, flow_kind="rigid"):
     """Inputs of the frame block [begin, end) of an nc_global-frame sequence.
 
     Returns numpy arrays: f (ny,nx,L), v for the pairs the block touches,
@@ -128,6 +162,7 @@ def make_block(ny, nx, nc_global, begin, end, factor=4, seed=1234, noise_seed=43
     f_state = f_all[:, :, s_lo - off:s_hi - off]
     f_block = f_all[:, :, begin - off:end - off]
     v = flows_backward(masks[:, :, p_lo - off:max(p_hi, p_lo) - off])
+    v = perturb_flows(v, range(p_lo, max(p_hi, p_lo)), flow_kind)
     out = {"f": f_block.cpu().numpy(), "f_state": f_state.cpu().numpy(), "v": v.cpu().numpy()}
     if with_truth:
         out["truth"] = g[:, :, begin - off:end - off].cpu().numpy()

@@ -17,16 +17,23 @@ pytestmark = pytest.mark.gpu
 KBLUR = orc.fspecial_gaussian(7, np.sqrt(0.6))
 
 
-def _worker(rank, world, port, nc, kappa, direction, iters, out_dir):
+def _worker(rank, world, port, nc, kappa, direction, iters, out_dir, backend="gloo"):
     import torch
     import torch.distributed as dist
     from superresolution_amd import sharding
     from superresolution_amd.solver import FrameBlockSolver
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    devno = rank if backend == "nccl" else 0
+    dev = "cuda:%d" % devno
+    if backend == "nccl":
+        torch.cuda.set_device(devno)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(devno)
         torch.cuda.set_stream(torch.cuda.Stream())
         f, v, occ = make_case(41, 8, 10, nc, flow="smooth", flow_scale=2.0, with_occ=True)
         P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
@@ -34,14 +41,15 @@ def _worker(rank, world, port, nc, kappa, direction, iters, out_dir):
         lo, hi = sharding.pairs_needed(a, b, nc)
         s0, s1 = sharding.state_frames_needed(a, b, nc)
         s = FrameBlockSolver(8, 10, 4, nc, a, b, alpha=P.alpha, kappa=kappa, h=0.0, flow_direction=direction,
-                             device=0, stream=torch.cuda.current_stream().cuda_stream)
+                             device=devno, stream=torch.cuda.current_stream().cuda_stream)
         s.set_lowres(f[:, :, a:b]); s.set_blur(KBLUR); s.set_flow(v[:, :, lo:hi, :], occ[:, :, lo:hi])
         s.set_state(P.u_up[:, :, s0:s1], P.u_up[:, :, s0:s1])
         s.init()
-        s.h = sharding.sharded_h(s, "cuda:0")
+        red = dev if backend == "nccl" else None
+        s.h = sharding.sharded_h(s, red)
         ex = sharding.HaloExchanger(sharding.halo_tensors(s), rank, world)
-        assert ex.staged
-        st = sharding.solve_sharded(s, ex, iters, 0.0, 10, "cuda:0")
+        assert ex.staged == (backend != "nccl")
+        st = sharding.solve_sharded(s, ex, iters, 0.0, 10, red)
         u, w = s.get_state()
         np.savez(os.path.join(out_dir, "r%d.npz" % rank), a=a, b=b, u=u, h=s.h,
                  res=np.array([st["res_primal"], st["res_dual"]]), **({} if w is None else {"w": w}))
@@ -54,10 +62,24 @@ def _worker(rank, world, port, nc, kappa, direction, iters, out_dir):
 @pytest.mark.parametrize("world,nc,kappa,direction", [(2, 5, 0.25, "backward"), (3, 6, float("nan"), "forward-backward"),
                                                       (3, 3, 0.25, "backward")])
 def test_two_processes_one_gpu(tmp_path, world, nc, kappa, direction):
+    _run_and_check(tmp_path, world, nc, kappa, direction, "gloo")
+
+
+@pytest.mark.parametrize("world,nc,kappa,direction", [(2, 5, 0.25, "backward"), (2, 4, float("nan"), "forward-backward")])
+def test_ranks_on_their_own_gpus_over_rccl(tmp_path, world, nc, kappa, direction):
+    """The device-to-device branch of the halo exchange (backend nccl = RCCL, frames sent from the
+    library's own buffers, stream-ordered waits).  Needs one GPU per rank."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))
+    _run_and_check(tmp_path, world, nc, kappa, direction, "nccl")
+
+
+def _run_and_check(tmp_path, world, nc, kappa, direction, backend):
     import torch.multiprocessing as mp
     iters = 30
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    mp.spawn(_worker, args=(world, port, nc, kappa, direction, iters, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, nc, kappa, direction, iters, str(tmp_path), backend), nprocs=world, join=True)
     f, v, occ = make_case(41, 8, 10, nc, flow="smooth", flow_scale=2.0, with_occ=True)
     P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
     x, _, chg = orc.pdhg(P, iters)
