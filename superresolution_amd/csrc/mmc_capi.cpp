@@ -35,6 +35,9 @@ struct mmc_handle {
     float h = 1.f;
     std::vector<void *> allocs;
     unsigned long long *scratch = nullptr;   // one frame of 64-bit words for mmc_init
+    int *ovf_cursor = nullptr;               // (L+1)*ntiles counters for building the overflow lists
+    size_t ovf_capacity = 0;                 // entries allocated for a.ovf_idx
+    size_t ovf_total = 0;                    // entries in use
     std::string err;
     bool profiling = false;
     std::vector<hipEvent_t> events;       // 4 per profiled iteration
@@ -164,6 +167,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
         const int q = (g.ntiles + 7) / 8;
         const int full = g.ntiles / q, rest = g.ntiles - full * q;     // classes 0..full-1 hold q tiles, class `full` the rest
         g.dv_tiles_r = make_fastdiv((unsigned)g.tiles_r);
+        g.dv_Ny = make_fastdiv((unsigned)g.Ny);
         g.dv_q = make_fastdiv((unsigned)q);
         g.dv_qlast = make_fastdiv((unsigned)(rest > 0 ? rest : q));
         // The second use of a frame's planes (scatter sources, warp taps) comes one sweep over the
@@ -199,6 +203,9 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     if ((rc = dev_alloc(h, &a.bbox, (size_t)(h->L + 1) * g.ntiles * 4)) != MMC_OK) return bail(rc);
     { float **fx[] = {&a.q1, &a.q2, &a.u0, &a.w0}; for (float **pp : fx) if ((rc = dev_alloc(h, pp, (size_t)g.N)) != MMC_OK) return bail(rc); }
     if ((rc = dev_alloc(h, &a.tbox, (size_t)h->L * g.ntiles * 4)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.bstat, (size_t)(h->L + 1) * g.ntiles * 3)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.ovf_ptr, (size_t)(h->L + 1) * g.ntiles + 1)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &h->ovf_cursor, (size_t)(h->L + 1) * g.ntiles)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &h->scratch, (size_t)g.N)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)) != MMC_OK) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MMC_ERR_HIP); }
@@ -212,6 +219,7 @@ extern "C" int mmc_destroy(mmc_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     for (void *p : h->eallocs) hipFree(p);
+    if (h->a.ovf_idx) hipFree(h->a.ovf_idx);
     for (hipEvent_t e : h->events) hipEventDestroy(e);
     for (hipEvent_t e : h->sweep_events) hipEventDestroy(e);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -681,7 +689,32 @@ extern "C" int mmc_init(mmc_handle *h) {
         HIPCHK(h, hipMemcpyAsync(a.bbox, bb.data(), bb.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
+    const size_t nslots = (size_t)(h->L + 1) * g.ntiles;
+    HIPCHK(h, hipMemsetAsync(a.bstat, 0, nslots * 3 * sizeof(unsigned long long), h->stream));
     HIPCHK(h, mmc_launch_init_warp(g, a, h->scratch, h->stream));
+    {
+        // sources outside their tile's rectangle: count, prefix sum on the host, then place
+        std::vector<int> cnt(nslots), ptr(nslots + 1, 0);
+        HIPCHK(h, hipMemsetAsync(h->ovf_cursor, 0, nslots * sizeof(int), h->stream));
+        HIPCHK(h, mmc_launch_init_overflow(g, a, false, h->ovf_cursor, h->stream));
+        HIPCHK(h, hipMemcpyAsync(cnt.data(), h->ovf_cursor, nslots * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        long long total = 0;
+        for (size_t i = 0; i < nslots; ++i) { ptr[i] = (int)total; total += cnt[i]; }
+        if (total > (long long)INT_MAX) return fail(h, MMC_ERR_UNSUPPORTED, "mmc_init: flow too irregular (overflow lists exceed 2^31 entries)");
+        ptr[nslots] = (int)total;
+        if ((size_t)total > h->ovf_capacity || !a.ovf_idx) {
+            if (a.ovf_idx) { HIPCHK(h, hipFree(a.ovf_idx)); a.ovf_idx = nullptr; h->ovf_capacity = 0; }
+            const size_t cap = std::max<size_t>((size_t)total + (size_t)total / 4, 1024);
+            HIPCHK(h, hipMalloc((void **)&a.ovf_idx, cap * sizeof(int)));
+            h->ovf_capacity = cap;
+        }
+        HIPCHK(h, hipMemcpyAsync(a.ovf_ptr, ptr.data(), (nslots + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ovf_cursor, 0, nslots * sizeof(int), h->stream));
+        HIPCHK(h, mmc_launch_init_overflow(g, a, true, h->ovf_cursor, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->ovf_total = (size_t)total;
+    }
     HIPCHK(h, mmc_launch_sanitize(g, a, h->stream));
     if (!h->have_h && !h->has_prev && !h->has_next) {
         // MultiframeMotionCoupling.m:431-437.  A block with neighbours holds only part of the two

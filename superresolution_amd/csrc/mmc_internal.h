@@ -26,6 +26,10 @@ enum { TILE_R = MMC_TILE_R, TILE_C = MMC_TILE_C, MMC_THREADS = MMC_NTHREADS };
 static_assert(TILE_R * TILE_C == 4 * MMC_THREADS && (TILE_R & (TILE_R - 1)) == 0, "tile must hold one row quad per thread");
 enum { MMC_MAX_CK = 40 };      // max side of the composite (sampling * blur) kernel
 enum { MMC_WARP_MAX = 2304 }; // floats of the warped frame a tile may stage in LDS per plane
+// Regular part of a tile's flow: displacements within these margins of the tile's mean.  The tap
+// region of the dual sweep must fit MMC_WARP_MAX: (TILE_R + 1 + 2*MR + 6 alignment) x (TILE_C + 1 + 2*MC).
+enum { MMC_TAP_MR = 4, MMC_TAP_MC = 5, MMC_SRC_MR = 4, MMC_SRC_MC = 4 };
+static_assert((MMC_TILE_R + 1 + 2 * MMC_TAP_MR + 6) * (MMC_TILE_C + 1 + 2 * MMC_TAP_MC) <= MMC_WARP_MAX, "tap region must fit its LDS buffer");
 enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
 enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device
 // MMC_STATIC_MAX_BLOCKS (public header): workgroups of k_h_partials that mmc_h_partials_static has room for
@@ -59,6 +63,7 @@ struct Geom {
                                // its padded height (multiple of 4), and the height of the kernel table shifted by wpad
     int tiles_r, tiles_c, ntiles;
     FastDiv dv_tiles_r;        // tile -> (tile row, tile column)
+    FastDiv dv_Ny;             // pixel index -> column
     FastDiv dv_q, dv_qlast;    // tiles per XCD class ((ntiles+7)/8) and of the last non-empty class
     FastDiv dv_PR;
     // Frames larger than about 2 Mpx: each XCD class walks its tile range in sub-ranges of `chunk`
@@ -102,8 +107,12 @@ struct Arrays {
     int *et_row, *et_ptr, *et_col; float *et_val;
     float *pcorr;              // E xbar_u, L*n (zero off the rows of E)
     float *ucorr;              // E' p, L*N (zero off the rows of E')
-    int *bbox;                 // [(L+1) pair slots][ntiles][4] = rmin,rmax,cmin,cmax of the SOURCES of a tile
-    int *tbox;                 // [L pair slots][ntiles][4] = rows/cols of the warped frame a tile's TAPS touch
+    // Sources of a target tile in the adjoint of the warp: a rectangle plus a list of the stragglers
+    int *bbox;                 // [(L+1) pair slots][ntiles][4] = rmin,rmax,cmin,cmax of the source rectangle
+    int *ovf_ptr;              // [(L+1)*ntiles + 1] offsets into ovf_idx
+    int *ovf_idx;              // pixel indices of the sources outside their tile's rectangle
+    unsigned long long *bstat; // [(L+1)][ntiles][3] sum of source-minus-tap rows, columns, source count (set-up only)
+    int *tbox;                 // [L pair slots][ntiles][4] = rows/cols of the warped frame staged for a tile's TAPS
     double *sums;              // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]
 };
 
@@ -112,6 +121,8 @@ hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int
 hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s);
 // `frame_words`: N 8-byte words of device memory
 hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *frame_words, hipStream_t s);
+// counts (fill = false) or places (fill = true) the sources outside their tile's rectangle; cursor: (L+1)*ntiles ints
+hipError_t mmc_launch_init_overflow(const Geom &g, const Arrays &a, bool fill, int *cursor, hipStream_t s);
 hipError_t mmc_launch_sanitize(const Geom &g, const Arrays &a, hipStream_t s);
 hipError_t mmc_launch_fold_occ(const Geom &g, float *vx, const uint8_t *occ, size_t count, hipStream_t s);
 hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s);

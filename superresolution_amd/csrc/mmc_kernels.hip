@@ -260,15 +260,18 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
             if (!pair_exists(g, q)) continue;
             const bool isIF = pair_is_IF(g, q);
             if ((which == 0) != isIF) continue;   // q=t-1 warps into t iff I-F; q=t iff F-I
-            const int *bb = a.bbox + ((size_t)(q + 1) * g.ntiles + tile) * 4;
+            const size_t slot = (size_t)(q + 1) * g.ntiles + tile;
+            const int *bb = a.bbox + slot * 4;
             const int rmin = bb[0], rmax = bb[1], cmin = bb[2], cmax = bb[3];
-            if (rmax < rmin || cmax < cmin) continue;
-            const int nr = rmax - rmin + 1, total = nr * (cmax - cmin + 1);
+            const int nr = rmax - rmin + 1, total = (rmax < rmin || cmax < cmin) ? 0 : nr * (cmax - cmin + 1);
+            const int ob = a.ovf_ptr[slot], novf = a.ovf_ptr[slot + 1] - ob;
             const float *vx = FR(a.vx, q), *vy = FR(a.vy, q);
             const float *s1p = FR(a.g1t, q), *s2p = FR(a.g2t, q);
-            for (int idx = threadIdx.x; idx < total; idx += MMC_THREADS) {
-                const int r = rmin + idx % nr, c = cmin + idx / nr;
-                const int j = r + g.Ny * c;
+            // the source rectangle, then the sources outside it
+            for (int idx = threadIdx.x; idx < total + novf; idx += MMC_THREADS) {
+                int r, c, j;
+                if (idx < total) { r = rmin + idx % nr; c = cmin + idx / nr; j = r + g.Ny * c; }
+                else { j = a.ovf_idx[ob + idx - total]; c = j / g.Ny; r = j - c * g.Ny; }
                 Taps tp = make_taps(g, r, c, vx[j], vy[j]);
                 if (!tp.valid) continue;
                 const float s1 = s1p[j];
@@ -470,12 +473,16 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
 
     // source boxes of the scatter below, fetched ahead of the barrier
     int4 sbox[2] = {make_int4(0, -1, 0, -1), make_int4(0, -1, 0, -1)};
+    int2 sovf[2] = {make_int2(0, 0), make_int2(0, 0)};          // [begin, end) of the tile's overflow list
     if (MODE != MODE_STEPS) {
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             const int q = which == 0 ? t - 1 : t;
-            if (pair_exists(g, q) && (which == 0) == pair_is_IF(g, q))
-                sbox[which] = *reinterpret_cast<const int4 *>(a.bbox + ((size_t)(q + 1) * g.ntiles + tile) * 4);
+            if (pair_exists(g, q) && (which == 0) == pair_is_IF(g, q)) {
+                const size_t slot = (size_t)(q + 1) * g.ntiles + tile;
+                sbox[which] = *reinterpret_cast<const int4 *>(a.bbox + slot * 4);
+                sovf[which] = make_int2(a.ovf_ptr[slot], a.ovf_ptr[slot + 1]);
+            }
         }
     }
 
@@ -526,12 +533,27 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
             const bool isIF = pair_is_IF(g, q);
             if ((which == 0) != isIF) continue;
             const int rmin = sbox[which].x, rmax = sbox[which].y, cmin = sbox[which].z, cmax = sbox[which].w;
-            if (rmax < rmin || cmax < cmin) continue;
             if (ABL(1)) continue;
-            const int nr = rmax - rmin + 1, total = nr * (cmax - cmin + 1);
+            const int nr = rmax - rmin + 1, total = (rmax < rmin || cmax < cmin) ? 0 : nr * (cmax - cmin + 1);
+            const int ob = sovf[which].x, novf = sovf[which].y - ob;
             const float inv_nr = fast_rcp((float)nr);
             const float *vx = FR(a.vx, q), *vy = FR(a.vy, q);
             const float *s1p = FR(a.g1t, q), *s2p = FR(a.g2t, q);
+            auto scatter_one = [&](int srow, int scol, float fx, float fy, float f1, float f2) {
+                Taps tp = make_taps(g, srow, scol, fx, fy);
+                if (!tp.valid) return;
+                const float s1 = f1;
+                const float s2 = (MODEL == MODEL_IC) ? kap * f2 - s1 : 0.f;
+                const double d1 = fx_scaled(s1), d2 = fx_scaled(s2);
+                const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
+                const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
+                const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
+                if (ABL(2)) { if (s1 == 12345.f && ra0 && cb1) acc1[0] = to_fx(1.0, d2); return; }
+                if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00, d2); if (CWS) fx_add(&acc3[a0 + TILE_R * b0], tp.w00, 1099511627776.0); }
+                if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10, d2); if (CWS) fx_add(&acc3[a1 + TILE_R * b0], tp.w10, 1099511627776.0); }
+                if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01, d2); if (CWS) fx_add(&acc3[a0 + TILE_R * b1], tp.w01, 1099511627776.0); }
+                if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11, d2); if (CWS) fx_add(&acc3[a1 + TILE_R * b1], tp.w11, 1099511627776.0); }
+            };
             for (int base = tid; base < total; base += MMC_THREADS * SCU) {
                 int sr[SCU], sc[SCU];
                 float fvx[SCU], fvy[SCU], fs1[SCU], fs2[SCU];
@@ -553,20 +575,14 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t
 #pragma unroll
                 for (int k = 0; k < SCU; ++k) {
                     if (base + k * MMC_THREADS >= total) continue;
-                    Taps tp = make_taps(g, sr[k], sc[k], fvx[k], fvy[k]);
-                    if (!tp.valid) continue;
-                    const float s1 = fs1[k];
-                    const float s2 = (MODEL == MODEL_IC) ? kap * fs2[k] - s1 : 0.f;
-                    const double d1 = fx_scaled(s1), d2 = fx_scaled(s2);
-                    const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
-                    const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
-                    const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
-                    if (ABL(2)) { if (s1 == 12345.f && ra0 && cb1) acc1[0] = to_fx(1.0, d2); continue; }
-                    if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00, d2); if (CWS) fx_add(&acc3[a0 + TILE_R * b0], tp.w00, 1099511627776.0); }
-                    if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10, d2); if (CWS) fx_add(&acc3[a1 + TILE_R * b0], tp.w10, 1099511627776.0); }
-                    if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01, d2); if (CWS) fx_add(&acc3[a0 + TILE_R * b1], tp.w01, 1099511627776.0); }
-                    if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11, d2); if (CWS) fx_add(&acc3[a1 + TILE_R * b1], tp.w11, 1099511627776.0); }
+                    scatter_one(sr[k], sc[k], fvx[k], fvy[k], fs1[k], fs2[k]);
                 }
+            }
+            // sources outside the rectangle (stray vectors): one gather each
+            for (int k = tid; k < novf; k += MMC_THREADS) {
+                const int js = a.ovf_idx[ob + k];
+                const int scol = fdiv(js, g.dv_Ny), srow = js - scol * g.Ny;
+                scatter_one(srow, scol, vx[js], vy[js], s1p[js], (MODEL == MODEL_IC) ? s2p[js] : 0.f);
             }
         }
         __syncthreads();
@@ -1069,7 +1085,9 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                 Taps tp = make_taps(g, r + i, c, fvx[i], fvy[i]);
                 valid[i] = tp.valid;
                 if (tp.valid) {
-                    if (use_lds) {
+                    // taps inside the staged region read LDS; a stray vector gathers from global memory
+                    const bool in_lds = use_lds && tp.r0 >= wrlo && tp.r1 < wrlo + WR && tp.c0 >= wclo && tp.c1 < wclo + WC;
+                    if (in_lds) {
                         tu = sample_lds(tp, wu, wrlo, wclo, WR) - (isIF ? uc[i] : idu[i]);
                         if (MODEL == MODEL_IC) tw = sample_lds(tp, ww, wrlo, wclo, WR) - (isIF ? wc[i] : idw[i]);
                     } else {
@@ -1269,10 +1287,33 @@ __global__ __launch_bounds__(MMC_THREADS) void k_corr_u(Geom g, Arrays a, int t0
 // one-off kernels
 // --------------------------------------------------------------------------
 
-// Column abs-sums of the motion-coupling operator and, per target tile, the
-// bounding box of the source pixels whose taps land in it.  Pass 1 (per pair q
-// whose warp samples frame wf): tap weights are summed per target pixel in
-// 64-bit fixed point (order-independent) and the tile boxes are widened.
+// Column abs-sums of the motion-coupling operator and the per-tile source regions of its
+// adjoint.  For a target tile T of the warped frame, the sources are the pixels of pair q with a
+// tap inside T.  With a regular flow they fill a rectangle the size of the tile, displaced by the
+// flow; a single stray vector (estimators produce them at occlusions) would blow its bounding box
+// up, so the region is described as a rectangle plus a list:
+//   pass 1  k_init_scatter  tap weights summed per target pixel in 64-bit fixed point
+//                           (order-independent), and per tile the sum of the source-minus-tap
+//                           displacements and the number of sources
+//   pass 2  k_init_srcbox   the rectangle: bounding box of the sources whose displacement lies
+//                           within MMC_SRC_MR rows / MMC_SRC_MC columns of the tile's mean
+//   pass 3  k_init_overflow<false>  number of sources of T that lie outside its rectangle
+//   pass 4  k_init_overflow<true>   their pixel indices, after a prefix sum on the host
+// The update sweep walks the rectangle (every pixel in it, whatever its displacement) and then
+// the list, so each source of T is visited exactly once.
+template <typename F>
+__device__ __forceinline__ void for_each_target_tile(const Geom &g, const Taps &tp, F fn) {
+    const int tr0 = tp.r0 / TILE_R, tr1 = tp.r1 / TILE_R, tc0 = tp.c0 / TILE_C, tc1 = tp.c1 / TILE_C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ttr = (k & 1) ? tr1 : tr0, ttc = (k & 2) ? tc1 : tc0;
+        if (k == 1 && tr1 == tr0) continue;
+        if (k == 2 && tc1 == tc0) continue;
+        if (k == 3 && (tr1 == tr0 || tc1 == tc0)) continue;
+        fn(ttr + g.tiles_r * ttc);
+    }
+}
+
 __global__ __launch_bounds__(MMC_THREADS) void k_init_scatter(Geom g, Arrays a, int q, fx64 *tmp) {
     const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
     if (j >= g.N) return;
@@ -1283,18 +1324,58 @@ __global__ __launch_bounds__(MMC_THREADS) void k_init_scatter(Geom g, Arrays a, 
     atomicAdd(&tmp[tp.i10], to_fx((double)tp.w10, 1099511627776.0));
     atomicAdd(&tmp[tp.i01], to_fx((double)tp.w01, 1099511627776.0));
     atomicAdd(&tmp[tp.i11], to_fx((double)tp.w11, 1099511627776.0));
+    fx64 *st = a.bstat + (size_t)(q + 1) * g.ntiles * 3;
+    for_each_target_tile(g, tp, [&](int tile) {
+        fx64 *b = st + (size_t)tile * 3;
+        atomicAdd(&b[0], (fx64)(long long)(r - tp.r0));
+        atomicAdd(&b[1], (fx64)(long long)(c - tp.c0));
+        atomicAdd(&b[2], (fx64)1);
+    });
+}
+
+// mean displacement (rounded down) of the sources of a tile
+__device__ __forceinline__ void tile_mean_disp(const fx64 *b, int &dr, int &dc) {
+    const long long n = (long long)b[2];
+    const long long sr = (long long)b[0], sc = (long long)b[1];
+    dr = (int)floor((double)sr / (double)n);
+    dc = (int)floor((double)sc / (double)n);
+}
+
+__global__ __launch_bounds__(MMC_THREADS) void k_init_srcbox(Geom g, Arrays a, int q) {
+    const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    const int r = j % g.Ny, c = j / g.Ny;
+    Taps tp = make_taps(g, r, c, FR(a.vx, q)[j], FR(a.vy, q)[j]);
+    if (!tp.valid) return;
+    const fx64 *st = a.bstat + (size_t)(q + 1) * g.ntiles * 3;
     int *bb = a.bbox + (size_t)(q + 1) * g.ntiles * 4;
-    const int tr0 = tp.r0 / TILE_R, tr1 = tp.r1 / TILE_R, tc0 = tp.c0 / TILE_C, tc1 = tp.c1 / TILE_C;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int ttr = (k & 1) ? tr1 : tr0, ttc = (k & 2) ? tc1 : tc0;
-        if (k == 1 && tr1 == tr0) continue;
-        if (k == 2 && tc1 == tc0) continue;
-        if (k == 3 && (tr1 == tr0 || tc1 == tc0)) continue;
-        int *b = bb + (size_t)(ttr + g.tiles_r * ttc) * 4;
+    for_each_target_tile(g, tp, [&](int tile) {
+        int dr, dc;
+        tile_mean_disp(st + (size_t)tile * 3, dr, dc);
+        if (abs(r - tp.r0 - dr) > MMC_SRC_MR || abs(c - tp.c0 - dc) > MMC_SRC_MC) return;
+        int *b = bb + (size_t)tile * 4;
         atomicMin(&b[0], r); atomicMax(&b[1], r);
         atomicMin(&b[2], c); atomicMax(&b[3], c);
-    }
+    });
+}
+
+// FILL = false: ovf_ptr[slot + 1] += 1 per source outside the rectangle of its target tile (the
+// host turns the counts into offsets); FILL = true: the indices, cursor[] counts what is placed.
+template <bool FILL>
+__global__ __launch_bounds__(MMC_THREADS) void k_init_overflow(Geom g, Arrays a, int q, int *cursor) {
+    const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    const int r = j % g.Ny, c = j / g.Ny;
+    Taps tp = make_taps(g, r, c, FR(a.vx, q)[j], FR(a.vy, q)[j]);
+    if (!tp.valid) return;
+    const int *bb = a.bbox + (size_t)(q + 1) * g.ntiles * 4;
+    for_each_target_tile(g, tp, [&](int tile) {
+        const int *b = bb + (size_t)tile * 4;
+        if (r >= b[0] && r <= b[1] && c >= b[2] && c <= b[3]) return;
+        const size_t slot = (size_t)(q + 1) * g.ntiles + tile;
+        if (FILL) a.ovf_idx[a.ovf_ptr[slot] + atomicAdd(&cursor[slot], 1)] = j;
+        else atomicAdd(&cursor[slot], 1);
+    });
 }
 
 // Pass 2 for frame t: cW = scattered weights + 1 for every unmasked row whose
@@ -1328,20 +1409,40 @@ __global__ __launch_bounds__(MMC_THREADS) void k_init_idq(Geom g, Arrays a, int 
     a.idq[(size_t)t * (g.N / 4 + 1) + qi] = (uint8_t)bits;
 }
 
-// Per (pair, tile): rows and columns of the warped frame touched by the taps of the tile's pixels.
+// Per (pair, tile): the rows and columns of the warped frame that the dual sweep stages in LDS for
+// the taps of the tile's pixels: the bounding box of the taps whose displacement lies within
+// MMC_TAP_MR rows / MMC_TAP_MC columns of the tile's mean displacement.  Pixels whose taps leave
+// that region (stray vectors, motion boundaries) gather from global memory in the sweep.
 __global__ __launch_bounds__(MMC_THREADS) void k_init_tapbox(Geom g, Arrays a) {
     __shared__ int box[4];
+    __shared__ int stat[3];
     const int t = blockIdx.y, tile = blockIdx.x;
-    if (threadIdx.x == 0) { box[0] = INT_MAX; box[1] = -1; box[2] = INT_MAX; box[3] = -1; }
+    if (threadIdx.x == 0) { box[0] = INT_MAX; box[1] = -1; box[2] = INT_MAX; box[3] = -1; stat[0] = stat[1] = stat[2] = 0; }
     __syncthreads();
-    if (pair_exists(g, t)) {
-        const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
+    const bool pex = pair_exists(g, t);
+    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
+    const float *vx = FR(a.vx, t), *vy = FR(a.vy, t);
+    if (pex) {
         for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) {
             const int r = tr * TILE_R + k % TILE_R, c = tc * TILE_C + k / TILE_R;
             if (r >= g.Ny || c >= g.Nx) continue;
             const int j = r + g.Ny * c;
-            Taps tp = make_taps(g, r, c, FR(a.vx, t)[j], FR(a.vy, t)[j]);
+            Taps tp = make_taps(g, r, c, vx[j], vy[j]);
             if (!tp.valid) continue;
+            // |displacement| < Ny, Nx and at most 1024 pixels per tile: the sums fit 32 bits
+            atomicAdd(&stat[0], tp.r0 - r); atomicAdd(&stat[1], tp.c0 - c); atomicAdd(&stat[2], 1);
+        }
+    }
+    __syncthreads();
+    if (pex && stat[2] > 0) {
+        const int dr = (int)floorf((float)stat[0] / (float)stat[2]), dc = (int)floorf((float)stat[1] / (float)stat[2]);
+        for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) {
+            const int r = tr * TILE_R + k % TILE_R, c = tc * TILE_C + k / TILE_R;
+            if (r >= g.Ny || c >= g.Nx) continue;
+            const int j = r + g.Ny * c;
+            Taps tp = make_taps(g, r, c, vx[j], vy[j]);
+            if (!tp.valid) continue;
+            if (abs(tp.r0 - r - dr) > MMC_TAP_MR || abs(tp.c0 - c - dc) > MMC_TAP_MC) continue;
             atomicMin(&box[0], tp.r0); atomicMax(&box[1], tp.r1);
             atomicMin(&box[2], tp.c0); atomicMax(&box[3], tp.c1);
         }
@@ -1531,21 +1632,42 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
     return hipGetLastError();
 }
 
-hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *frame_words, hipStream_t s) {
-    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS), block(MMC_THREADS);
-    fx64 *tmp = static_cast<fx64 *>(frame_words);
+// Pairs whose warp samples a local frame (their adjoint scatters into it): pair t-1 of frame t if
+// that pair is 'I-F', pair t if it is 'F-I'.
+template <typename F>
+static void for_each_scattering_pair(const Geom &g, F fn) {
     auto exists = [&](int q) { int gq = g.frame_begin + q; return q >= -1 && q <= g.L - 1 && gq >= 0 && gq <= g.nc_global - 2; };
     auto is_if = [&](int q) { return g.dir == 1 ? true : g.dir == 0 ? false : ((g.frame_begin + q) & 1) == 0; };
     for (int t = 0; t < g.L; ++t) {
+        if (exists(t - 1) && is_if(t - 1)) fn(t, t - 1);
+        if (exists(t) && !is_if(t)) fn(t, t);
+    }
+}
+
+hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *frame_words, hipStream_t s) {
+    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS), block(MMC_THREADS);
+    fx64 *tmp = static_cast<fx64 *>(frame_words);
+    for (int t = 0; t < g.L; ++t) {
         hipError_t e = hipMemsetAsync(tmp, 0, (size_t)g.N * sizeof(fx64), s);
         if (e != hipSuccess) return e;
-        if (exists(t - 1) && is_if(t - 1)) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, t - 1, tmp);
-        if (exists(t) && !is_if(t)) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, t, tmp);
+        for_each_scattering_pair(g, [&](int tf, int q) {
+            if (tf == t) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, q, tmp);
+        });
         hipLaunchKernelGGL(k_init_finalize, grid, block, 0, s, g, a, t, tmp);
         if (g.Ny % 4 == 0)
             hipLaunchKernelGGL(k_init_idq, dim3((g.N / 4 + MMC_THREADS - 1) / MMC_THREADS), block, 0, s, g, a, t);
     }
+    for_each_scattering_pair(g, [&](int, int q) { hipLaunchKernelGGL(k_init_srcbox, grid, block, 0, s, g, a, q); });
     hipLaunchKernelGGL(k_init_tapbox, dim3(g.ntiles, g.L), block, 0, s, g, a);
+    return hipGetLastError();
+}
+
+hipError_t mmc_launch_init_overflow(const Geom &g, const Arrays &a, bool fill, int *cursor, hipStream_t s) {
+    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS), block(MMC_THREADS);
+    for_each_scattering_pair(g, [&](int, int q) {
+        if (fill) hipLaunchKernelGGL(k_init_overflow<true>, grid, block, 0, s, g, a, q, cursor);
+        else hipLaunchKernelGGL(k_init_overflow<false>, grid, block, 0, s, g, a, q, cursor);
+    });
     return hipGetLastError();
 }
 

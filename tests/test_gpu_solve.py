@@ -94,6 +94,49 @@ def test_solve_parity_violent_flow():
     assert rel_l2(u, u_ref) < TOL
 
 
+def _with_outliers(v, seed, fraction, amplitude):
+    """Replaces a fraction of the vectors by uniform ones in [-amplitude, amplitude]^2."""
+    rng = np.random.default_rng(seed)
+    v = v.copy()
+    Ny, Nx, npairs, _ = v.shape
+    for i in range(npairs):
+        idx = rng.choice(Ny * Nx, size=max(int(fraction * Ny * Nx), 1), replace=False)
+        r, c = idx % Ny, idx // Ny
+        v[r, c, i, :] = rng.uniform(-amplitude, amplitude, (idx.size, 2))
+    return v.astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("direction,kappa", [("backward", 0.25), ("forward-backward", 0.25), ("forward", float("nan"))])
+def test_solve_parity_flow_with_outliers(direction, kappa):
+    """A smooth flow in which 1 % of the vectors are strays of up to 60 pixels (what an estimator
+    leaves at occlusions).  The source rectangles and tap regions stay tight around the regular
+    part of the flow; the strays go through the per-tile overflow lists of the primal sweep and
+    the per-pixel global gather of the dual sweep."""
+    f, v, occ = make_case(35, 48, 28, 3, flow="smooth", flow_scale=1.5, with_occ=True)
+    v = _with_outliers(v, 7, 0.01, 60.0)
+    P, x, chg, u_ref, w_ref, u, w, st, e = _run(f, v, occ, kappa, direction, 60)
+    assert rel_l2(u, u_ref) < TOL
+    if w_ref is not None:
+        assert np.abs(w - w_ref).max() < TOL
+    e_ref = orc.primal_energy(P, x)
+    assert abs(e - e_ref) <= 1e-3 * abs(e_ref)
+
+
+def test_motion_boundary_inside_tiles():
+    """Two motions 20 pixels apart split every tile: no pixel is close to the tile's mean
+    displacement, so every source goes through the overflow lists and every tap through the
+    global gather."""
+    f, v, occ = make_case(36, 32, 24, 3, flow="zero")
+    Ny, Nx = v.shape[:2]
+    half = (np.arange(Ny)[:, None] // 8 + np.arange(Nx)[None, :] // 8) % 2 == 0
+    for i in range(v.shape[2]):
+        v[:, :, i, 0] = np.where(half, 10.3, -9.6)
+        v[:, :, i, 1] = np.where(half, -7.2, 12.4)
+    v = v.astype(np.float32).astype(np.float64)
+    P, x, chg, u_ref, w_ref, u, w, st, e = _run(f, v, occ, 0.25, "backward", 40)
+    assert rel_l2(u, u_ref) < TOL
+
+
 @pytest.mark.parametrize("factor,ny,nx", [(2, 14, 18), (3, 7, 8)])
 def test_solve_parity_other_zoom_factors(factor, ny, nx):
     """Update sweeps of the generic-factor row-quad kernels (zoom 2) and of the scalar kernels
