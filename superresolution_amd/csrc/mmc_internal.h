@@ -27,9 +27,9 @@ static_assert(TILE_R * TILE_C == 4 * MMC_THREADS && (TILE_R & (TILE_R - 1)) == 0
 enum { MMC_MAX_CK = 40 };      // max side of the composite (sampling * blur) kernel
 enum { MMC_WARP_MAX = 2304 }; // floats of the warped frame a tile may stage in LDS per plane
 // Regular part of a tile's flow: displacements within these margins of the tile's mean.  The tap
-// region of the dual sweep must fit MMC_WARP_MAX: (TILE_R + 1 + 2*MR + 6 alignment) x (TILE_C + 1 + 2*MC).
+// region of the dual sweep must fit MMC_WARP_MAX: (TILE_R + 1 + 2*MR + 6 alignment + 1 pitch) x (TILE_C + 1 + 2*MC).
 enum { MMC_TAP_MR = 4, MMC_TAP_MC = 5, MMC_SRC_MR = 4, MMC_SRC_MC = 4 };
-static_assert((MMC_TILE_R + 1 + 2 * MMC_TAP_MR + 6) * (MMC_TILE_C + 1 + 2 * MMC_TAP_MC) <= MMC_WARP_MAX, "tap region must fit its LDS buffer");
+static_assert((MMC_TILE_R + 1 + 2 * MMC_TAP_MR + 6 + 1) * (MMC_TILE_C + 1 + 2 * MMC_TAP_MC) <= MMC_WARP_MAX, "tap region must fit its LDS buffer");
 enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
 enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device
 // MMC_STATIC_MAX_BLOCKS (public header): workgroups of k_h_partials that mmc_h_partials_static has room for

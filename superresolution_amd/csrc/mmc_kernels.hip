@@ -383,8 +383,24 @@ __device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
     *reinterpret_cast<float4 *>(p) = make_float4(s[0], s[1], s[2], s[3]);
 }
 
+// Tuning switches of the row-quad sweeps (defaults are the measured best).
+#ifndef MMC_TAP_ODD_PITCH
+#define MMC_TAP_ODD_PITCH 1     // odd LDS pitch of the dual sweep's tap windows (conflict-free reads)
+#endif
+#ifndef MMC_DATA_QUAD
+#define MMC_DATA_QUAD 1         // data term of the dual sweep summed by groups of four lanes, no second barrier
+#endif
+#ifndef MMC_SKIP_NOPAIR
+#define MMC_SKIP_NOPAIR 0       // 1: frames without a pair skip their temporal dual planes (measured slower: a wave per SIMD less)
+#endif
+#ifndef MMC_OCC_PRIMAL
+#define MMC_OCC_PRIMAL 1
+#endif
+#ifndef MMC_OCC_DUAL
+#define MMC_OCC_DUAL 1
+#endif
 template <int MODEL, int MODE, bool REDUCE, int F>
-__global__ __launch_bounds__(MMC_THREADS) void k_primal4(Geom g, Arrays a, int t0, int nf) {
+__global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     // In the update sweep the tap weights are scattered along with the duals, which yields the
     // scattered part of cW without reading the cW plane (4 bytes per pixel less).
@@ -953,7 +969,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0
 // low-res dual p of the tile from it: wave w sums the composite-kernel columns
 // n = w, w+4, ... for every low-res pixel, the four partial sums meet in LDS.
 template <int MODEL, int MODE, bool REDUCE, int F>
-__global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0, int nf) {
+__global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     const int f = F > 0 ? F : g.f;
     const int tid = threadIdx.x;
@@ -984,7 +1000,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
     // Rows/columns of the warped frame that this tile's taps touch (from mmc_init), rows widened
     // to whole quads.  If the region fits, it is staged in LDS with 16-byte loads and the 4 taps
     // per pixel are LDS reads; otherwise (violent flow) they are gathered from global memory.
-    int wrlo = 0, wclo = 0, WR = 0, WC = 0;
+    int wrlo = 0, wclo = 0, WR = 0, WC = 0, WP = 1;
     bool use_lds = false;
     if (pex && MODE != MODE_STEPS && !ABL(1024)) {
         const int *tb = a.tbox + ((size_t)t * g.ntiles + tile) * 4;
@@ -993,7 +1009,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
             wclo = tb[2];
             WR = (tb[1] | 3) - wrlo + 1;
             WC = tb[3] - wclo + 1;
-            use_lds = WR * WC <= MMC_WARP_MAX;
+            // Odd pitch: a wave's 16 row quads x 4 columns read rows 4 apart, which an even pitch folds
+            // onto 16 of the 64 LDS banks (4-way conflicts); with an odd pitch all 64 addresses differ mod 64.
+            WP = WR + MMC_TAP_ODD_PITCH;
+            use_lds = WP * WC <= MMC_WARP_MAX;
         }
     }
 
@@ -1018,8 +1037,14 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
             if (r + 4 < g.Ny) wbelow = wb[j + 4];
         }
         if (MODE == MODE_UPDATE) {
-            ld4(o1t, FR(a.g1t, t) + j); ld4(o1x, FR(a.g1x, t) + j); ld4(o1y, FR(a.g1y, t) + j);
-            if (MODEL == MODEL_IC) { ld4(o2t, FR(a.g2t, t) + j); ld4(o2x, FR(a.g2x, t) + j); ld4(o2y, FR(a.g2y, t) + j); }
+            // a frame without a pair (the last of the sequence) has no temporal rows: their duals stay 0
+            // and their planes are neither read nor written
+            const bool tpl = pex || !MMC_SKIP_NOPAIR;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o1t[i] = o2t[i] = 0.f;
+            if (tpl) ld4(o1t, FR(a.g1t, t) + j);
+            ld4(o1x, FR(a.g1x, t) + j); ld4(o1y, FR(a.g1y, t) + j);
+            if (MODEL == MODEL_IC) { if (tpl) ld4(o2t, FR(a.g2t, t) + j); ld4(o2x, FR(a.g2x, t) + j); ld4(o2y, FR(a.g2y, t) + j); }
         }
     }
 
@@ -1058,9 +1083,16 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
             if (kr < 0) { --kc; kr += QR; }
             if (kr >= QR) { ++kc; kr -= QR; }
             const int src = wrlo + 4 * kr + g.Ny * (wclo + kc);
-            *reinterpret_cast<float4 *>(wu + 4 * kr + WR * kc) = *reinterpret_cast<const float4 *>(ubW + src);
-            if (MODEL == MODEL_IC)
-                *reinterpret_cast<float4 *>(ww + 4 * kr + WR * kc) = *reinterpret_cast<const float4 *>(wbW + src);
+            const float4 vu = *reinterpret_cast<const float4 *>(ubW + src);
+            float *du = wu + 4 * kr + WP * kc;
+            if (MMC_TAP_ODD_PITCH) { du[0] = vu.x; du[1] = vu.y; du[2] = vu.z; du[3] = vu.w; }
+            else *reinterpret_cast<float4 *>(du) = vu;
+            if (MODEL == MODEL_IC) {
+                const float4 vw = *reinterpret_cast<const float4 *>(wbW + src);
+                float *dw = ww + 4 * kr + WP * kc;
+                if (MMC_TAP_ODD_PITCH) { dw[0] = vw.x; dw[1] = vw.y; dw[2] = vw.z; dw[3] = vw.w; }
+                else *reinterpret_cast<float4 *>(dw) = vw;
+            }
         }
     }
     if (MODE != MODE_STEPS) __syncthreads();
@@ -1088,8 +1120,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                     // taps inside the staged region read LDS; a stray vector gathers from global memory
                     const bool in_lds = use_lds && tp.r0 >= wrlo && tp.r1 < wrlo + WR && tp.c0 >= wclo && tp.c1 < wclo + WC;
                     if (in_lds) {
-                        tu = sample_lds(tp, wu, wrlo, wclo, WR) - (isIF ? uc[i] : idu[i]);
-                        if (MODEL == MODEL_IC) tw = sample_lds(tp, ww, wrlo, wclo, WR) - (isIF ? wc[i] : idw[i]);
+                        tu = sample_lds(tp, wu, wrlo, wclo, WP) - (isIF ? uc[i] : idu[i]);
+                        if (MODEL == MODEL_IC) tw = sample_lds(tp, ww, wrlo, wclo, WP) - (isIF ? wc[i] : idw[i]);
                     } else {
                         tu = sample(tp, ubW) - (isIF ? uc[i] : idu[i]);
                         if (MODEL == MODEL_IC) tw = sample(tp, wbW) - (isIF ? wc[i] : idw[i]);
@@ -1167,7 +1199,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                     part[1] += n1t[i] * n1t[i] + n1x[i] * n1x[i] + n1y[i] * n1y[i];
                 }
             }
-            st4(g1t, n1t); st4(g1x, n1x); st4(g1y, n1y);
+            if (pex || !MMC_SKIP_NOPAIR) st4(g1t, n1t);
+            st4(g1x, n1x); st4(g1y, n1y);
             if (MODEL == MODEL_IC) {
                 float n2t[4], n2x[4], n2y[4];
 #pragma unroll
@@ -1183,7 +1216,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
                         part[1] += n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i];
                     }
                 }
-                st4(g2t, n2t); st4(g2x, n2x); st4(g2y, n2y);
+                if (pex || !MMC_SKIP_NOPAIR) st4(g2t, n2t);
+                st4(g2x, n2x); st4(g2y, n2y);
                 if (g.fixed && g.frame_begin + t == 0) {
                     // q <- q + (xbar - x0): F*(q) = <x0, q>, identity rows, step 1 (:560-564)
                     float q1o[4], q2o[4], x0u[4], x0w[4], q1n[4], q2n[4];
@@ -1205,7 +1239,48 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
 
     // ---- data term: p <- clamp(p + s (A xbar_u - f), -1, 1)   (:496) --------
     float epart = 0.f;
-    if (MODE != MODE_STEPS && !ABL(512)) {
+    // Zoom 4: four adjacent lanes share a low-res pixel and split the columns of the composite
+    // kernel among them (lane part takes columns part, part+4, ...); two lane exchanges add the
+    // four partial sums, lane 0 of the group updates p.  No second barrier, no partial sums in LDS;
+    // the loads of p, f and the step size are in flight while the sums are formed.
+    const bool QUAD = MMC_DATA_QUAD && VEC && 4 * nlr == MMC_THREADS;
+    if (QUAD && MODE != MODE_STEPS && !ABL(512)) {
+        const int lp = tid >> 2, part4 = tid & 3;
+        const int Rl = lp % LRR, Cl = lp / LRR;
+        const int R = r0 / f + Rl, C = c0 / f + Cl;
+        const bool owner = part4 == 0 && R < g.ny && C < g.nx;
+        const size_t o = (size_t)t * g.n + (owner ? R + g.ny * C : 0);
+        float po = 0.f, fo = 0.f, sg = 0.f;
+        if (owner) {
+            if (MODE == MODE_UPDATE) { po = a.p[o]; sg = a.sigp[R + g.ny * C]; }
+            if (MODE == MODE_UPDATE || MODE == MODE_ENERGY) fo = a.f[o];
+        }
+        const int mq = g.MPq >> 2;
+        float s = 0.f;
+        for (int nn = part4; nn < g.CW; nn += 4) {
+            const float4 *col = reinterpret_cast<const float4 *>(ubl + f * Rl + SR * (f * Cl + nn));
+            const float4 *ck = reinterpret_cast<const float4 *>(ckq + g.MPq * nn);
+            for (int m4 = 0; m4 < mq; ++m4) {
+                const float4 cv = ck[m4], dv = col[m4];
+                s += cv.x * dv.x + cv.y * dv.y + cv.z * dv.z + cv.w * dv.w;
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (owner) {
+            if (a.pcorr) s += a.pcorr[o];
+            if (MODE == MODE_RAW) {
+                a.p[o] = s;
+            } else if (MODE == MODE_ENERGY) {
+                epart += fabsf(s - fo);
+            } else {
+                const float pn = fminf(fmaxf(po + sg * (s - fo), -1.f), 1.f);
+                a.p[o] = pn;
+                if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; }
+            }
+        }
+    }
+    if (!QUAD && MODE != MODE_STEPS && !ABL(512)) {
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         for (int lp = lane; lp < nlr; lp += 64) {
             const int Rl = lp % LRR, Cl = lp / LRR;
@@ -1233,6 +1308,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual4(Geom g, Arrays a, int t0,
         __syncthreads();
     }
     for (int lp = tid; lp < nlr; lp += MMC_THREADS) {
+        if (QUAD && MODE != MODE_STEPS) break;
         const int Rl = lp % LRR, Cl = lp / LRR;
         const int R = r0 / f + Rl, C = c0 / f + Cl;
         if (R >= g.ny || C >= g.nx) continue;
