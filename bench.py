@@ -204,6 +204,13 @@ def main():
     begin, end = sharding.partition_frames(nc, world)[rank]
     L = end - begin
     model = "ic" if not (np.isnan(args.kappa) or args.kappa == 1) else "single"
+    # Hardware-counter collection (rocprofv3 --pmc) over torch's own rendering kernels, which include
+    # MIOpen's convolution search, stalls before the first library call; under a profiler the
+    # inputs are therefore rendered on the host.
+    profiled = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_"))]
+    if profiled and not args.host_inputs:
+        log("profiler environment (%s): rendering inputs on the host" % profiled[0])
+        args.host_inputs = True
     in_dev = "cpu" if args.host_inputs else dev
 
     log("rank %d: rendering frames [%d, %d) of %d on %s" % (rank, begin, end, nc, in_dev))

@@ -159,7 +159,12 @@ int mmc_num_flow_pairs(const mmc_handle *h);
 /* Start point: u and w for the local frames followed, when the block has a
  * next neighbour, by that neighbour's first frame (needed once, for h).
  * w may be NULL when the model has no w (kappa = 1 or NaN).  Duals start at 0.
- * Replaces u_vec.val / w_vec.val, MultiframeMotionCoupling.m:445-456. */
+ * Replaces u_vec.val / w_vec.val, MultiframeMotionCoupling.m:445-456.
+ * u == NULL (and w == NULL): the library computes u = w = imresize(f, factor)
+ * with the bicubic kernel on the device from the data given to mmc_set_lowres
+ * (the u_up of MultiframeMotionCoupling.m:415-419; the start point of :686-687).
+ * A block with a next neighbour then still lacks that neighbour's first frame:
+ * exchange the halo once (send_prev -> recv_next) before mmc_h_partials. */
 int mmc_set_state(mmc_handle *h, const float *u, const float *w);
 int mmc_num_state_frames(const mmc_handle *h);
 

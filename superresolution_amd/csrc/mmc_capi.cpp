@@ -316,19 +316,52 @@ extern "C" int mmc_set_flow(mmc_handle *h, const float *v, const uint8_t *occ) {
     return MMC_OK;
 }
 
+// Keys cubic (a = -1/2), the kernel of imresize's 'bicubic'
+static double keys_cubic(double x) {
+    x = std::fabs(x);
+    if (x <= 1.0) return 1.5 * x * x * x - 2.5 * x * x + 1.0;
+    if (x <= 2.0) return -0.5 * x * x * x + 2.5 * x * x - 4.0 * x + 2.0;
+    return 0.0;
+}
+
+// imresize's contribution rule for an integer zoom: output sample x (1-based) sits at
+// u = x/zoom + (1 - 1/zoom)/2, taps floor(u - 2) + {0..5} (1-based input indices)
+static void make_bicubic_tab(int zoom, BicubicTab *tab) {
+    memset(tab, 0, sizeof(*tab));
+    for (int ph = 0; ph < zoom; ++ph) {
+        const double x = ph + 1.0;                         // first output sample of this phase; low-res index 0
+        const double u = x / zoom + 0.5 * (1.0 - 1.0 / zoom);
+        const double left = std::floor(u - 2.0);
+        double w[MMC_BICUBIC_TAPS], sum = 0.0;
+        for (int k = 0; k < MMC_BICUBIC_TAPS; ++k) { w[k] = keys_cubic(u - (left + k)); sum += w[k]; }
+        for (int k = 0; k < MMC_BICUBIC_TAPS; ++k) tab->w[ph][k] = (float)(w[k] / sum);
+        tab->first[ph] = (int)left - 1;                    // 0-based offset from the low-res index x_out / zoom
+    }
+}
+
 extern "C" int mmc_set_state(mmc_handle *h, const float *u, const float *w) {
     REQUIRE_HANDLE(h);
     int rc = use_device(h); if (rc) return rc;
     const Geom &g = h->g;
-    if (!u) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_state: null u");
-    if (g.model == MODEL_IC && !w) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_state: this model needs w");
+    if (u && g.model == MODEL_IC && !w) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_state: this model needs w");
+    if (!u && w) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_state: w without u");
     const size_t nloc = (size_t)h->L * g.N, nall = (size_t)(h->L + h->has_next) * g.N;
     Arrays &a = h->a;
-    HIPCHK(h, hipMemcpyAsync(a.u + g.N, u, nloc * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(a.ub + g.N, u, nall * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (g.model == MODEL_IC) {
-        HIPCHK(h, hipMemcpyAsync(a.w + g.N, w, nloc * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(a.wb + g.N, w, nall * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (u) {
+        HIPCHK(h, hipMemcpyAsync(a.u + g.N, u, nloc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(a.ub + g.N, u, nall * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if (g.model == MODEL_IC) {
+            HIPCHK(h, hipMemcpyAsync(a.w + g.N, w, nloc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(a.wb + g.N, w, nall * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        }
+    } else {
+        // u = w = imresize(f, factor), computed on the device (MultiframeMotionCoupling.m:415-419, :686-687)
+        if (!h->have_f) return fail(h, MMC_ERR_STATE, "mmc_set_state: the bicubic start point needs the low-resolution data (mmc_set_lowres)");
+        if (g.f > MMC_BICUBIC_MAX_ZOOM)
+            return fail(h, MMC_ERR_UNSUPPORTED, "mmc_set_state: the built-in bicubic start point covers zoom factors up to 8; pass u and w");
+        BicubicTab tab;
+        make_bicubic_tab(g.f, &tab);
+        HIPCHK(h, mmc_launch_bicubic_start(g, a, tab, h->stream));
     }
     // duals start at zero
     const size_t fs = frame_slots(h) * (size_t)g.N * sizeof(float);

@@ -125,6 +125,12 @@ hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *frame_word
 hipError_t mmc_launch_init_overflow(const Geom &g, const Arrays &a, bool fill, int *cursor, hipStream_t s);
 hipError_t mmc_launch_sanitize(const Geom &g, const Arrays &a, hipStream_t s);
 hipError_t mmc_launch_fold_occ(const Geom &g, float *vx, const uint8_t *occ, size_t count, hipStream_t s);
+// Bicubic start point (MultiframeMotionCoupling.m:415-419): per output phase (index mod zoom) the six
+// normalised Keys weights and the offset of the first tap relative to (index / zoom).
+enum { MMC_BICUBIC_MAX_ZOOM = 8, MMC_BICUBIC_TAPS = 6 };
+struct BicubicTab { float w[MMC_BICUBIC_MAX_ZOOM][MMC_BICUBIC_TAPS]; int first[MMC_BICUBIC_MAX_ZOOM]; };
+// u, ub (and w, wb when the model has w) of the local frames <- imresize(f, zoom, 'bicubic')
+hipError_t mmc_launch_bicubic_start(const Geom &g, const Arrays &a, const BicubicTab &tab, hipStream_t s);
 hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s);
 
 // Failure of an entry point that has no handle and must not allocate: `literal` (a string literal)

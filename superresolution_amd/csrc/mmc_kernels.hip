@@ -1593,6 +1593,34 @@ __global__ __launch_bounds__(MMC_THREADS) void k_h_final(const double *part, int
     if (threadIdx.x < 2) result[threadIdx.x] = red[threadIdx.x][0];
 }
 
+// u_up = imresize(f, zoom) with the bicubic kernel (MultiframeMotionCoupling.m:415-419): output
+// sample x (1-based) sits at x/zoom + (1 - 1/zoom)/2 in input coordinates, six taps from
+// floor(that - 2), Keys weights (a = -1/2) normalised to unit sum, indices beyond the edge
+// replicate the edge pixel.  For an integer zoom the weights depend on x mod zoom only.
+__global__ __launch_bounds__(MMC_THREADS) void k_bicubic_start(Geom g, Arrays a, BicubicTab tab) {
+    const int t = blockIdx.y;
+    const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    const int c = fdiv(j, g.dv_Ny), r = j - c * g.Ny;
+    const int R = r / g.f, pr = r - R * g.f, C = c / g.f, pc = c - C * g.f;
+    const float *fl = a.f + (size_t)t * g.n;
+    float acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < MMC_BICUBIC_TAPS; ++b) {
+        const int cc = min(max(C + tab.first[pc] + b, 0), g.nx - 1);
+        float col = 0.f;
+#pragma unroll
+        for (int k = 0; k < MMC_BICUBIC_TAPS; ++k) {
+            const int rr = min(max(R + tab.first[pr] + k, 0), g.ny - 1);
+            col += tab.w[pr][k] * fl[rr + g.ny * cc];
+        }
+        acc += tab.w[pc][b] * col;
+    }
+    FR(a.u, t)[j] = acc;
+    FR(a.ub, t)[j] = acc;
+    if (g.model == MODEL_IC) { FR(a.w, t)[j] = acc; FR(a.wb, t)[j] = acc; }
+}
+
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
@@ -1758,6 +1786,12 @@ hipError_t mmc_launch_fold_occ(const Geom &g, float *vx, const uint8_t *occ, siz
     if (count == 0) return hipSuccess;
     dim3 grid((unsigned)((count + MMC_THREADS - 1) / MMC_THREADS)), block(MMC_THREADS);
     hipLaunchKernelGGL(k_fold_occ, grid, block, 0, s, vx, occ, count);
+    return hipGetLastError();
+}
+
+hipError_t mmc_launch_bicubic_start(const Geom &g, const Arrays &a, const BicubicTab &tab, hipStream_t s) {
+    dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS, g.L), block(MMC_THREADS);
+    hipLaunchKernelGGL(k_bicubic_start, grid, block, 0, s, g, a, tab);
     return hipGetLastError();
 }
 

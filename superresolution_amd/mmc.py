@@ -16,7 +16,7 @@ import warnings
 import numpy as np
 
 from ._capi import MMCError
-from .imresize import imresize_bicubic, upsample_sequence
+from .imresize import imresize_bicubic
 
 _POS_FLOW = ("forward", "backward", "forward-backward")
 _POS_FW = ("hip", "prost", "flexBox", "flexBox-vector")
@@ -190,9 +190,9 @@ class MultiframeMotionCoupling(object):
         s.set_lowres(self._imageSequenceSmall)
         s.set_blur(self.k)                                           # :373-375
         s.set_flow(v, self._occ)                                     # :389-412
-        u_up = upsample_sequence(self._imageSequenceSmall, int(self.factor))   # :415-419
-        # h is always taken from the bicubic estimate (:432-437), whatever the start point is (:446-456)
-        s.set_state(u_up, u_up)
+        # u_up = imresize(LR, factor) (:415-419) is computed on the device; h is always taken from it
+        # (:432-437), whatever the start point is (:446-456)
+        s.set_state()
         if nc > 1:
             warpPix, gradPix = s.h_partials()
             if not (warpPix > 0 and gradPix > 0):
@@ -202,6 +202,7 @@ class MultiframeMotionCoupling(object):
         else:
             s.h = 1.0
         if self._u is not None or self._w is not None:
+            u_up, _ = s.get_state()
             s.set_state(u_up if self._u is None else self._u, u_up if self._w is None else self._w)
         if self._u0_frame is not None:                               # :535-572
             if np.isnan(self.kappa) or self.kappa == 1:

@@ -128,7 +128,13 @@ class FrameBlockSolver(object):
         self._check(self._lib.mmc_set_flow(self._h, fptr(v),
                                            None if o is None else o.ctypes.data_as(C.POINTER(C.c_uint8))))
 
-    def set_state(self, u, w=None):
+    def set_state(self, u=None, w=None):
+        """Start point; u=None: bicubic estimate of the low-res data, computed on the device."""
+        if u is None:
+            if w is not None:
+                raise ValueError("w without u")
+            self._check(self._lib.mmc_set_state(self._h, None, None))
+            return
         nf = self.num_state_frames
         u = as_f32(u)
         if u.shape != (self.Ny, self.Nx, nf):

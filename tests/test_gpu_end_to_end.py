@@ -71,6 +71,29 @@ def test_h_comes_from_the_bicubic_estimate_on_reinit():
     m.close()
 
 
+@pytest.mark.parametrize("factor,kappa", [(4, 0.25), (2, float("nan")), (3, 1.0)])
+def test_bicubic_start_point_on_the_device(factor, kappa):
+    """mmc_set_state(h, NULL, NULL): u = w = imresize(f, factor) computed by the library
+    (MultiframeMotionCoupling.m:415-419).  Against the oracle's float64 imresize to 1e-6, and h
+    from it equal to the h of a host-computed start point to 1e-5."""
+    from superresolution_amd.solver import FrameBlockSolver
+    ny, nx, nc = 13, 9, 3
+    f, v, _ = make_case(51, ny, nx, nc, factor=factor, flow="smooth", flow_scale=1.5)
+    u_ref = np.stack([orc.imresize(f[:, :, i], factor) for i in range(nc)], axis=2)
+    hs = []
+    for start in (None, u_ref):
+        with FrameBlockSolver(ny, nx, factor, nc, kappa=kappa, sampling="stride") as s:
+            s.set_lowres(f); s.set_blur(KBLUR); s.set_flow(v)
+            s.set_state(start)
+            u, w = s.get_state()
+            assert np.abs(u - u_ref).max() <= 1e-6
+            if w is not None:
+                assert np.array_equal(u, w)
+            s.init()
+            hs.append(s.h)
+    assert abs(hs[0] - hs[1]) <= 1e-5 * hs[1]
+
+
 def test_colour_input_and_presets():
     """4-D RGB input goes through Y of rgb2ycbcr (:110-119) and comes back as RGB (:1022-1046);
     'fastest' switches to the additive model (:283-290) and stops on the 1e-4 tolerance."""
