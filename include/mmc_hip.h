@@ -255,6 +255,50 @@ int mmc_get_state(mmc_handle *h, float *u, float *w);
  * ||A u - f||_1 + regulariser, for logging (the quantity prost prints). */
 int mmc_energy(mmc_handle *h, double *value);
 
+/* ---- One sequence on several GPUs from ONE host thread ------------------------
+ * The caller of solveU (MultiframeMotionCoupling.m:977-986) is one MATLAB session,
+ * i.e. one process; a group lets that process spread the sequence over the GPUs of
+ * the node and keep the reference's shape of the call: one solve in, u and w out.
+ * A group cuts [0, nc_global) into nblocks contiguous frame blocks (remainders to
+ * the first blocks), gives each block a handle of its own on device_ids[i]
+ * (device_ids == NULL: all on params.device; several blocks may share a device)
+ * and runs the iteration on all of them: each block's sweeps on its own stream,
+ * the two frame-sized messages per block boundary and iteration (mmc_halo) as
+ * peer-to-peer copies on a copy stream per block, ordered by events so that a copy
+ * overlaps with the sweeps over the frames that do not need it.  With params.h <= 0
+ * mmc_group_init adds mmc_h_partials up over the blocks (:431-437).
+ * params describes the whole sequence: frame_begin = 0, frame_end = nc_global,
+ * stream = NULL.  Host buffers have the sizes of the whole sequence and the layouts
+ * of the per-block calls of the same name: f ny x nx x nc; v Ny x Nx x (nc-1) x 2;
+ * occ Ny x Nx x (nc-1); u, w Ny x Nx x nc (NULL, NULL: bicubic start point).
+ * For equal h a group's iterates are bit-for-bit those of one block over the whole
+ * sequence (the sweeps are order-independent); residuals are sums of doubles added
+ * in another order.  Calls on one group must come from one thread at a time. */
+typedef struct mmc_group mmc_group;
+int mmc_group_create(const mmc_params *params, int nblocks, const int32_t *device_ids, mmc_group **out);
+int mmc_group_destroy(mmc_group *g);
+/* g == NULL: the last mmc_group_create failure of the calling thread */
+const char *mmc_group_last_error(const mmc_group *g);
+int mmc_group_num_blocks(const mmc_group *g);
+int mmc_group_block_range(const mmc_group *g, int block, int32_t *frame_begin, int32_t *frame_end, int32_t *device);
+/* The handle of one block, e.g. for mmc_set_profiling / mmc_get_sweep_profile / mmc_energy;
+ * it stays owned by the group.  NULL for a bad index. */
+mmc_handle *mmc_group_block_handle(mmc_group *g, int block);
+int mmc_group_set_lowres(mmc_group *g, const float *f);
+int mmc_group_set_blur(mmc_group *g, const float *k, int kh, int kw);
+int mmc_group_set_sampling_taps(mmc_group *g, const int32_t *first_y, const float *w_y, int taps_y,
+                                const int32_t *first_x, const float *w_x, int taps_x);
+int mmc_group_set_flow(mmc_group *g, const float *v, const uint8_t *occ);
+int mmc_group_set_state(mmc_group *g, const float *u, const float *w);
+int mmc_group_set_fixed_frame(mmc_group *g, const float *u0, const float *w0);
+int mmc_group_init(mmc_group *g);
+int mmc_group_get_h(const mmc_group *g, float *value);
+int mmc_group_set_h(mmc_group *g, float value);
+/* As mmc_solve; the residuals are those of the whole sequence. */
+int mmc_group_solve(mmc_group *g, int max_iters, float tol, int check_every,
+                    mmc_stats *stats, mmc_progress_cb cb, void *user);
+int mmc_group_get_state(mmc_group *g, float *u, float *w);
+
 /* ---- Test hooks: the operators of the sweeps without the prox maps. ---------
  * K x for x = (u, w): out_p is n*L, out_g1/out_g2 are component-major
  * [temporal; dx; dy] of N*L each (additive model: g1 = temporal only,

@@ -7,13 +7,16 @@ library has not been built.
 """
 from ._capi import MMCError  # noqa: F401
 
-__all__ = ["MMCError", "FrameBlockSolver", "MultiframeMotionCoupling", "MultiframeMotionCouplingAlternating"]
+__all__ = ["MMCError", "FrameBlockSolver", "SequenceGroupSolver", "MultiframeMotionCoupling", "MultiframeMotionCouplingAlternating"]
 
 
 def __getattr__(name):
     if name == "FrameBlockSolver":
         from .solver import FrameBlockSolver
         return FrameBlockSolver
+    if name == "SequenceGroupSolver":
+        from .solver import SequenceGroupSolver
+        return SequenceGroupSolver
     if name == "MultiframeMotionCoupling":
         from .mmc import MultiframeMotionCoupling
         return MultiframeMotionCoupling

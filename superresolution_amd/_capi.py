@@ -89,6 +89,23 @@ SIGNATURES = {
     "mmc_get_sweep_profile": (C.c_int, [_H, _dp, C.POINTER(C.c_int)]),
     "mmc_get_state": (C.c_int, [_H, _fp, _fp]),
     "mmc_energy": (C.c_int, [_H, _dp]),
+    "mmc_group_create": (C.c_int, [C.POINTER(mmc_params), C.c_int, C.POINTER(C.c_int32), C.POINTER(_H)]),
+    "mmc_group_destroy": (C.c_int, [_H]),
+    "mmc_group_last_error": (C.c_char_p, [_H]),
+    "mmc_group_num_blocks": (C.c_int, [_H]),
+    "mmc_group_block_range": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mmc_group_block_handle": (_H, [_H, C.c_int]),
+    "mmc_group_set_lowres": (C.c_int, [_H, _fp]),
+    "mmc_group_set_blur": (C.c_int, [_H, _fp, C.c_int, C.c_int]),
+    "mmc_group_set_sampling_taps": (C.c_int, [_H, C.POINTER(C.c_int32), _fp, C.c_int, C.POINTER(C.c_int32), _fp, C.c_int]),
+    "mmc_group_set_flow": (C.c_int, [_H, _fp, _u8p]),
+    "mmc_group_set_state": (C.c_int, [_H, _fp, _fp]),
+    "mmc_group_set_fixed_frame": (C.c_int, [_H, _fp, _fp]),
+    "mmc_group_init": (C.c_int, [_H]),
+    "mmc_group_get_h": (C.c_int, [_H, _fp]),
+    "mmc_group_set_h": (C.c_int, [_H, C.c_float]),
+    "mmc_group_solve": (C.c_int, [_H, C.c_int, C.c_float, C.c_int, C.POINTER(mmc_stats), PROGRESS_CB, C.c_void_p]),
+    "mmc_group_get_state": (C.c_int, [_H, _fp, _fp]),
     "mmc_debug_apply_K": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),
     "mmc_debug_apply_KT": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "mmc_debug_steps": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),

@@ -287,18 +287,20 @@ extern "C" int mmc_set_sampling_taps(mmc_handle *h, const int32_t *first_y, cons
 extern "C" int mmc_num_flow_pairs(const mmc_handle *h) { return h ? h->npairs : MMC_ERR_INVALID_ARG; }
 extern "C" int mmc_num_state_frames(const mmc_handle *h) { return h ? h->L + h->has_next : MMC_ERR_INVALID_ARG; }
 
-extern "C" int mmc_set_flow(mmc_handle *h, const float *v, const uint8_t *occ) {
+// Flow of the block's pairs from two host planes (displacement along columns, along rows), each
+// Ny x Nx x npairs; occ as in mmc_set_flow.
+int mmc_internal_set_flow_planes(mmc_handle *h, const float *vcol, const float *vrow, const uint8_t *occ) {
     REQUIRE_HANDLE(h);
     int rc = use_device(h); if (rc) return rc;
     const Geom &g = h->g;
     if (h->npairs > 0) {
-        if (!v) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_flow: null flow");
+        if (!vcol || !vrow) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_flow: null flow");
         // pair with global index gq lives in frame slot (gq - frame_begin) + 1
         const size_t slot0 = (size_t)(h->pair_lo - g.frame_begin + 1);
         const size_t cnt = (size_t)h->npairs * g.N;
         float *dvx = h->a.vx + slot0 * g.N, *dvy = h->a.vy + slot0 * g.N;
-        HIPCHK(h, hipMemcpyAsync(dvx, v, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(dvy, v + cnt, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(dvx, vcol, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(dvy, vrow, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
         if (occ) {
             uint8_t *docc = nullptr;
             HIPCHK(h, hipMalloc((void **)&docc, cnt));
@@ -315,6 +317,14 @@ extern "C" int mmc_set_flow(mmc_handle *h, const float *v, const uint8_t *occ) {
     h->inited = false;
     return MMC_OK;
 }
+
+extern "C" int mmc_set_flow(mmc_handle *h, const float *v, const uint8_t *occ) {
+    REQUIRE_HANDLE(h);
+    const size_t cnt = (size_t)h->npairs * h->g.N;
+    return mmc_internal_set_flow_planes(h, v, v ? v + cnt : nullptr, occ);
+}
+
+hipStream_t mmc_internal_stream(const mmc_handle *h) { return h ? h->stream : nullptr; }
 
 // Keys cubic (a = -1/2), the kernel of imresize's 'bicubic'
 static double keys_cubic(double x) {

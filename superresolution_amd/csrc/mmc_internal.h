@@ -136,3 +136,8 @@ hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s);
 // Failure of an entry point that has no handle and must not allocate: `literal` (a string literal)
 // becomes what mmc_last_error(NULL) returns on this thread; returns `code`.
 int mmc_static_fail(int code, const char *literal);
+
+// Used by the group driver (mmc_group.cpp), which owns one handle per frame block.
+struct mmc_handle;
+hipStream_t mmc_internal_stream(const mmc_handle *h);
+int mmc_internal_set_flow_planes(mmc_handle *h, const float *vcol, const float *vrow, const uint8_t *occ);

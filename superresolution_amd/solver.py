@@ -292,3 +292,179 @@ class FrameBlockSolver(object):
         tw = np.empty(N * L, np.float32) if self.has_w else None
         self._check(self._lib.mmc_debug_steps_update(self._h, fptr(tu), fptr(tw)))
         return tu, tw
+
+
+class SequenceGroupSolver(object):
+    """One sequence cut into frame blocks that one host thread drives on one or several GPUs
+    (mmc_group_* of the C ABI): what a single-process caller such as the MEX gateway uses to reach
+    every GPU of the node while keeping the call shape of MultiframeMotionCoupling.m:977-986.
+    Arrays are those of the whole sequence, in the layouts of FrameBlockSolver."""
+
+    def __init__(self, ny, nx, factor, nc, nblocks=1, devices=None, alpha=0.01, kappa=0.25, h=0.0,
+                 flow_direction="backward", sampling="average", device=0):
+        self._lib = _capi.load_library()
+        self._g = C.c_void_p()
+        if flow_direction not in _DIRECTIONS:
+            raise ValueError("Invalid flow direction.")
+        if sampling not in _SAMPLINGS:
+            raise MMCError(-4, "sampling must be 'average', 'stride' or 'taps', got '%s'" % sampling)
+        p = _capi.mmc_params()
+        p.size = C.sizeof(_capi.mmc_params)
+        p.version = _capi.MMC_ABI_VERSION
+        p.ny, p.nx, p.factor = int(ny), int(nx), int(factor)
+        p.nc_global, p.frame_begin, p.frame_end = int(nc), 0, int(nc)
+        p.alpha, p.kappa, p.h = float(alpha), float(kappa), float(h)
+        p.flow_direction = _DIRECTIONS[flow_direction]
+        p.sampling = _SAMPLINGS[sampling]
+        p.device = int(device)
+        p.stream = None
+        ids = None
+        if devices is not None:
+            if len(devices) != nblocks:
+                raise ValueError("one device ordinal per block")
+            ids = (C.c_int32 * nblocks)(*[int(d) for d in devices])
+        rc = self._lib.mmc_group_create(C.byref(p), int(nblocks), ids, C.byref(self._g))
+        if rc != 0:
+            raise MMCError(rc, self._lib.mmc_group_last_error(None).decode())
+        self.ny, self.nx, self.factor, self.nc = int(ny), int(nx), int(factor), int(nc)
+        self.Ny, self.Nx = self.ny * self.factor, self.nx * self.factor
+        self.has_w = not (np.isnan(kappa) or kappa == 1)
+        self._cb_keepalive = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MMCError(rc, self._lib.mmc_group_last_error(self._g).decode())
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g.value:
+            self._lib.mmc_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def num_blocks(self):
+        return self._lib.mmc_group_num_blocks(self._g)
+
+    def block_range(self, i):
+        """(frame_begin, frame_end, device) of block i."""
+        a, b, d = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.mmc_group_block_range(self._g, int(i), C.byref(a), C.byref(b), C.byref(d)))
+        return a.value, b.value, d.value
+
+    def block_sweep_profile(self, i):
+        """Summed duration (ms) and count of block i's profiled sweeps (after set_profiling)."""
+        hb = self._lib.mmc_group_block_handle(self._g, int(i))
+        ms = (C.c_double * 2)()
+        n = (C.c_int * 2)()
+        rc = self._lib.mmc_get_sweep_profile(hb, ms, n)
+        if rc != 0:
+            raise MMCError(rc, self._lib.mmc_last_error(hb).decode())
+        return {"primal_ms": ms[0], "dual_ms": ms[1], "primal_calls": n[0], "dual_calls": n[1]}
+
+    def set_profiling(self, enable=True):
+        for i in range(self.num_blocks):
+            hb = self._lib.mmc_group_block_handle(self._g, i)
+            self._lib.mmc_set_profiling(hb, int(bool(enable)))
+
+    def set_lowres(self, f):
+        f = as_f32(f)
+        if f.shape != (self.ny, self.nx, self.nc):
+            raise ValueError("low-res sequence must be %s, got %s" % ((self.ny, self.nx, self.nc), f.shape))
+        self._check(self._lib.mmc_group_set_lowres(self._g, fptr(f)))
+
+    def set_blur(self, k):
+        if k is None or np.size(k) == 0:
+            self._check(self._lib.mmc_group_set_blur(self._g, None, 0, 0))
+            return
+        k = as_f32(np.atleast_2d(k))
+        self._check(self._lib.mmc_group_set_blur(self._g, fptr(k), k.shape[0], k.shape[1]))
+
+    def set_sampling_taps(self, first_y, w_y, first_x, w_x):
+        fy = np.ascontiguousarray(first_y, dtype=np.int32)
+        fx = np.ascontiguousarray(first_x, dtype=np.int32)
+        wy = np.ascontiguousarray(w_y, dtype=np.float32)
+        wx = np.ascontiguousarray(w_x, dtype=np.float32)
+        if fy.shape != (self.ny,) or wy.ndim != 2 or wy.shape[0] != self.ny:
+            raise ValueError("row taps must be (%d,) and (%d, T)" % (self.ny, self.ny))
+        if fx.shape != (self.nx,) or wx.ndim != 2 or wx.shape[0] != self.nx:
+            raise ValueError("column taps must be (%d,) and (%d, T)" % (self.nx, self.nx))
+        i32 = C.POINTER(C.c_int32)
+        self._check(self._lib.mmc_group_set_sampling_taps(self._g, fy.ctypes.data_as(i32), fptr(wy), wy.shape[1],
+                                                          fx.ctypes.data_as(i32), fptr(wx), wx.shape[1]))
+
+    def set_flow(self, v, occ=None):
+        if self.nc == 1:
+            self._check(self._lib.mmc_group_set_flow(self._g, None, None))
+            return
+        v = as_f32(v).reshape((self.Ny, self.Nx, -1, 2), order="F")
+        if v.shape[2] != self.nc - 1:
+            raise ValueError("flow must hold %d pairs, got %d" % (self.nc - 1, v.shape[2]))
+        o = None
+        if occ is not None:
+            o = np.asfortranarray(np.asarray(occ).reshape((self.Ny, self.Nx, self.nc - 1), order="F") != 0,
+                                  dtype=np.uint8)
+        self._check(self._lib.mmc_group_set_flow(self._g, fptr(v),
+                                                 None if o is None else o.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def set_state(self, u=None, w=None):
+        if u is None:
+            if w is not None:
+                raise ValueError("w without u")
+            self._check(self._lib.mmc_group_set_state(self._g, None, None))
+            return
+        u = as_f32(u)
+        if u.shape != (self.Ny, self.Nx, self.nc):
+            raise ValueError("state must be %s, got %s" % ((self.Ny, self.Nx, self.nc), u.shape))
+        w = as_f32(u if w is None else w) if self.has_w else None
+        self._check(self._lib.mmc_group_set_state(self._g, fptr(u), fptr(w)))
+
+    def set_fixed_frame(self, u0, w0):
+        a = None if u0 is None else as_f32(u0)
+        b = None if w0 is None else as_f32(w0)
+        self._check(self._lib.mmc_group_set_fixed_frame(self._g, fptr(a), fptr(b)))
+
+    def init(self):
+        self._check(self._lib.mmc_group_init(self._g))
+
+    @property
+    def h(self):
+        v = C.c_float()
+        self._check(self._lib.mmc_group_get_h(self._g, C.byref(v)))
+        return float(v.value)
+
+    @h.setter
+    def h(self, value):
+        self._check(self._lib.mmc_group_set_h(self._g, float(value)))
+
+    def solve(self, max_iters, tol=0.0, check_every=0, callback=None):
+        st = _capi.mmc_stats()
+        if callback is not None:
+            def _cb(it, stp, _user):
+                s = stp.contents
+                return int(bool(callback(it, {"res_primal": s.res_primal, "res_dual": s.res_dual,
+                                              "seconds": s.solve_seconds})))
+            cb = _capi.PROGRESS_CB(_cb)
+        else:
+            cb = _capi.PROGRESS_CB()
+        self._cb_keepalive = cb
+        self._check(self._lib.mmc_group_solve(self._g, int(max_iters), float(tol), int(check_every),
+                                              C.byref(st), cb, None))
+        return {"iterations": st.iterations, "converged": bool(st.converged),
+                "res_primal": st.res_primal, "res_dual": st.res_dual, "seconds": st.solve_seconds}
+
+    def get_state(self):
+        u = np.empty((self.Ny, self.Nx, self.nc), dtype=np.float32, order="F")
+        w = np.empty_like(u) if self.has_w else None
+        self._check(self._lib.mmc_group_get_state(self._g, fptr(u), fptr(w)))
+        return u, w

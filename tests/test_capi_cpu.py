@@ -110,3 +110,31 @@ def test_static_entry_point_validates_before_touching_the_gpu():
     p = _params(factor=0)
     assert lib.mmc_create(C.byref(p), C.byref(h)) == -1
     assert "Input must be > 0" in lib.mmc_last_error(None).decode()
+
+
+def test_group_create_validates_before_touching_the_gpu():
+    lib = _capi.load_library()
+    g = C.c_void_p()
+    p = _params()
+    assert lib.mmc_group_create(C.byref(p), 4, None, C.byref(g)) == -1 and not g.value
+    assert "between 1 and nc_global" in lib.mmc_group_last_error(None).decode()
+    p = _params(frame_begin=1)
+    assert lib.mmc_group_create(C.byref(p), 1, None, C.byref(g)) == -1
+    assert "whole sequence" in lib.mmc_group_last_error(None).decode()
+    p = _params(stream=C.c_void_p(64))
+    assert lib.mmc_group_create(C.byref(p), 1, None, C.byref(g)) == -1
+    assert "params.stream must be NULL" in lib.mmc_group_last_error(None).decode()
+    assert lib.mmc_group_destroy(None) == 0
+    assert lib.mmc_group_init(None) == -1
+    assert not lib.mmc_group_block_handle(None, 0)
+
+
+def test_group_create_without_gpu_reports_no_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _capi.load_library()
+    g = C.c_void_p()
+    p = _params()
+    assert lib.mmc_group_create(C.byref(p), 2, None, C.byref(g)) == -5 and not g.value
+    assert "no HIP device" in lib.mmc_group_last_error(None).decode()
