@@ -229,6 +229,8 @@ extern "C" int mmc_destroy(mmc_handle *h) {
 
 static int use_device(mmc_handle *h) {
     HIPCHK(h, hipSetDevice(h->prm.device));
+    // the launchers report hipGetLastError(): drop what an unrelated earlier call of this thread left behind
+    (void)hipGetLastError();
     return MMC_OK;
 }
 

@@ -87,7 +87,8 @@ extern "C" mmc_handle *mmc_group_block_handle(mmc_group *g, int block) {
 extern "C" int mmc_group_destroy(mmc_group *g) {
     if (!g) return MMC_OK;
     for (GroupBlock &b : g->blocks) {
-        hipSetDevice(b.device);
+        if (!b.h) continue;                 // never created: no stream, no events
+        if (hipSetDevice(b.device) != hipSuccess) (void)hipGetLastError();
         if (b.copy) { hipStreamSynchronize(b.copy); hipStreamDestroy(b.copy); }
         for (hipEvent_t e : {b.primal_done, b.dual_done, b.xbar_sent, b.duals_sent}) if (e) hipEventDestroy(e);
         if (b.h) mmc_destroy(b.h);
@@ -106,6 +107,15 @@ extern "C" int mmc_group_create(const mmc_params *p, int nblocks, const int32_t 
     if (nblocks <= 0 || nblocks > p->nc_global)
         return gfail(nullptr, MMC_ERR_INVALID_ARG, "mmc_group_create: need between 1 and nc_global blocks (one frame per block at least)");
     if (p->stream) return gfail(nullptr, MMC_ERR_INVALID_ARG, "mmc_group_create: a group makes its own streams; params.stream must be NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return gfail(nullptr, MMC_ERR_NO_DEVICE, "mmc_group_create: no HIP device available");
+    }
+    for (int i = 0; i < nblocks; ++i) {
+        const int d = device_ids ? device_ids[i] : p->device;
+        if (d < 0 || d >= ndev) return gfail(nullptr, MMC_ERR_INVALID_ARG, "mmc_group_create: device ordinal out of range");
+    }
     mmc_group *g = new mmc_group();
     g->prm = *p;
     g->nc = p->nc_global;
