@@ -137,14 +137,68 @@ def imresize(img, scale, method='bicubic', antialiasing=True):
 # --------------------------------------------------------------------------
 
 
+def _pchip_slopes(y):
+    """Derivatives of MATLAB's pchip on the grid 1..n (Fritsch-Carlson; unit spacing): zero where
+    the secant slopes change sign or vanish, their harmonic mean otherwise; the three-point,
+    shape-preserving end formula of pchip.m (pchipend)."""
+    n = len(y)
+    del_ = np.diff(y)
+    d = np.zeros(n)
+    if n == 2:
+        d[:] = del_[0]
+        return d
+    for k in range(1, n - 1):
+        if del_[k - 1] * del_[k] > 0:
+            d[k] = 2.0 * del_[k - 1] * del_[k] / (del_[k - 1] + del_[k])
+
+    def end(d1, d2):
+        e = (3.0 * d1 - d2) / 2.0
+        if np.sign(e) != np.sign(d1):
+            e = 0.0
+        elif np.sign(d1) != np.sign(d2) and abs(e) > abs(3.0 * d1):
+            e = 3.0 * d1
+        return e
+    d[0] = end(del_[0], del_[1])
+    d[-1] = end(del_[-1], del_[-2])
+    return d
+
+
+def _interp1_uniform(y, xi, method):
+    """interp1(1:n, y, xi, method) for xi inside [1, n], method 'pchip' or 'v5cubic'
+    (samplingOperator.m:99-106 calls it on the columns of the identity).
+    'v5cubic': cubic convolution of Keys (a = -1/2) on the data extended at either end by
+    3*y(1) - 3*y(2) + y(3) (and its mirror image), as MATLAB documents for uniformly spaced points."""
+    n = len(y)
+    xi = np.asarray(xi, dtype=np.float64)
+    k = np.clip(np.floor(xi).astype(int), 1, n - 1)          # interval [k, k+1], 1-based
+    s = xi - k
+    if method == 'pchip':
+        d = _pchip_slopes(np.asarray(y, dtype=np.float64))
+        y0, y1, d0, d1 = y[k - 1], y[k], d[k - 1], d[k]
+        h00 = (1 + 2 * s) * (1 - s) ** 2
+        h10 = s * (1 - s) ** 2
+        h01 = s * s * (3 - 2 * s)
+        h11 = s * s * (s - 1)
+        return h00 * y0 + h10 * d0 + h01 * y1 + h11 * d1
+    if method == 'v5cubic':
+        ye = np.concatenate([[3 * y[0] - 3 * y[1] + y[2]], y, [3 * y[-1] - 3 * y[-2] + y[-3]]])
+        # ye[m] = y(m) in 1-based numbering of y, m = 0 .. n+1
+        return (((2 - s) * s - 1) * s * ye[k - 1] + ((3 * s - 5) * s * s + 2) * ye[k]
+                + ((4 - 3 * s) * s + 1) * s * ye[k + 1] + (s - 1) * s * s * ye[k + 2]) / 2.0
+    raise ValueError(method)
+
+
 def _Dim1Matrix(inputDim, targetDim, method, kernel, antialiasing):
     """samplingOperator.m:89-146.  Returns S with shape inputDim x targetDim."""
     factor = inputDim / targetDim
     if method in ('nearest', 'linear', 'pchip', 'v5cubic') and not antialiasing:
         # samplingOperator.m:99-106 (interp1 with the identity matrix)
-        if method not in ('nearest', 'linear'):
-            raise NotImplementedError("interp1 method '%s' is not restated" % method)
         targetPos = np.arange(1 + factor / 2.0, inputDim + 1 + 1e-12, factor) - 0.5
+        if method in ('pchip', 'v5cubic'):
+            # interp1(1:n, eye(n), targetPos, method): every column of the identity on its own
+            Y = np.eye(inputDim)
+            cols = [_interp1_uniform(Y[:, i], targetPos, method) for i in range(inputDim)]
+            return sp.csr_matrix(np.stack(cols, axis=0))
         S = np.zeros((inputDim, len(targetPos)))
         for j, tp in enumerate(targetPos):
             if method == 'nearest':

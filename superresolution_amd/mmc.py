@@ -5,7 +5,8 @@ Same public surface: constructor name/value options (:98-218), public
 properties (:31-57), `init` (:221-313), `run` (:316-336), `result1`/`result2`.
 The one addition is the framework value 'hip' (the default here), which takes
 the place of 'prost': init builds no sparse matrix but hands the raw arrays to
-libmmc_hip (init_u_hip), and solveU calls its solve.  Optical-flow estimation
+libmmc_hip (init_u_hip), and solveU calls its solve.  framework = 'flexBox'
+runs the same library with the presets of init_u_flexBox (:690-902).  Optical-flow estimation
 (init_v0, :905-971) is not part of this package: flows are passed in with
 'flowField', as variants/testfile_epicFlow.m does.
 """
@@ -140,9 +141,8 @@ class MultiframeMotionCoupling(object):
             raise ValueError(' "Fastest" mode can currently only be used with the "prost" framework')
         if self.framework == "prost":                                # :253-258
             raise RuntimeError("prost framework not found on path, or no GPUs found with prost")
-        if self.framework in ("flexBox", "flexBox-vector"):          # :259-269
-            raise RuntimeError("Cannot find flexBox framework, please install the framework and"
-                               " add it to your MATLAB path")
+        if self.framework == "flexBox-vector":                       # in posFW (:236) but not dispatched (:299-307)
+            raise ValueError("Invalid framework string.")
         self._dimsLarge = (int(self.factor) * self._dimsSmall[0], int(self.factor) * self._dimsSmall[1])   # :273
         self._tol_pd = 1e-6 if self.comp_mode == "accurate" else 1e-4                                      # :276-280
         if self.comp_mode == "fastest":                              # :283-290
@@ -154,17 +154,36 @@ class MultiframeMotionCoupling(object):
         if self._flowCompute:                                        # :293-296
             raise MMCError(-4, "optical-flow estimation (init_v0) stays on the reference path: "
                                "construct the object with 'flowField'")
-        self._init_u_hip()
+        if self.framework == "flexBox":
+            self._init_u_flexBox()
+        else:
+            self._init_u_hip()
         if self.verbose > 0:
             print("Initialization finished")
 
-    def _init_u_hip(self):
+    def _init_u_flexBox(self):
+        """The problem init_u_flexBox (:690-902) hands to flexBox.runAlgorithm, solved by the HIP path:
+        iteration caps 2500 / 800 (:798-802), start point u = bicubic estimate and w = 0 (only the
+        first nc of the 2nc primal variables are set, :893-896), 'average' without anti-aliasing is
+        the block mean of superpixelOperator for every zoom factor (:707-708), additive model and
+        'forward-backward' are the reference's errors (:699-702, :776-778).
+        Deviation: the 'backward' branch of the reference couples u + w in its temporal rows
+        ({Id,-Wi,Id,-Wi}, :864) where its 'forward' branch (:834) and the prost path (:490-491)
+        couple u - w; this path solves the u - w model for both directions."""
+        if isinstance(self.kappa, float) and (math.isnan(self.kappa) or self.kappa == 0):
+            raise ValueError("Additive warp and full separation not implemented yet for flexBox.")   # :699-702
+        if self.flowDirection == "forward-backward":
+            raise ValueError("todo")                                                                  # :776-778
+        block_mean = self.interpMethod == "average" and not self.interpAA
+        self._init_u_hip(max_iters=(2500, 800), w_start_zero=True, block_mean=block_mean)
+
+    def _init_u_hip(self, max_iters=(7500, 2500), w_start_zero=False, block_mean=False):
         """What init_u_prost (:346-574) does, without the sparse matrices."""
         from .solver import FrameBlockSolver
         ny, nx = self._dimsSmall
         Ny, Nx = self._dimsLarge
         nc = self._numFrames
-        iters = 7500 if self.comp_mode == "accurate" else 2500      # :352-356
+        iters = max_iters[0] if self.comp_mode == "accurate" else max_iters[1]      # :352-356
         self._opts = {"max_iters": iters, "tol": self._tol_pd}
         v = np.asarray(self._v, dtype=np.float64)
         if v.shape != (Ny, Nx, max(nc - 1, 0), 2) and not (nc == 2 and v.shape == (Ny, Nx, 2)):
@@ -180,12 +199,13 @@ class MultiframeMotionCoupling(object):
                              device=self.device)
         if not builtin:
             from .sampling import dim1_taps
-            try:
+            if block_mean:      # superpixelOperator: mean over factor x factor blocks
+                f = int(self.factor)
+                fy, wy = np.arange(0, Ny, f, dtype=np.int32), np.full((ny, f), 1.0 / f, np.float32)
+                fx, wx = np.arange(0, Nx, f, dtype=np.int32), np.full((nx, f), 1.0 / f, np.float32)
+            else:
                 fy, wy = dim1_taps(Ny, ny, self.interpMethod, self.interpKernel, bool(self.interpAA))
                 fx, wx = dim1_taps(Nx, nx, self.interpMethod, self.interpKernel, bool(self.interpAA))
-            except NotImplementedError as e:
-                s.close()
-                raise MMCError(-4, str(e))
             s.set_sampling_taps(fy, wy, fx, wx)
         s.set_lowres(self._imageSequenceSmall)
         s.set_blur(self.k)                                           # :373-375
@@ -201,9 +221,10 @@ class MultiframeMotionCoupling(object):
             s.h = warpPix / gradPix
         else:
             s.h = 1.0
-        if self._u is not None or self._w is not None:
+        if self._u is not None or self._w is not None or w_start_zero:
             u_up, _ = s.get_state()
-            s.set_state(u_up if self._u is None else self._u, u_up if self._w is None else self._w)
+            w_default = np.zeros_like(u_up) if w_start_zero else u_up
+            s.set_state(u_up if self._u is None else self._u, w_default if self._w is None else self._w)
         if self._u0_frame is not None:                               # :535-572
             if np.isnan(self.kappa) or self.kappa == 1:
                 raise MMCError(-1, "u0_frame/w0_frame need the infimal-convolution model (kappa not 1, not NaN)")

@@ -138,3 +138,12 @@ def test_group_create_without_gpu_reports_no_device():
     p = _params()
     assert lib.mmc_group_create(C.byref(p), 2, None, C.byref(g)) == -5 and not g.value
     assert "no HIP device" in lib.mmc_group_last_error(None).decode()
+
+
+def test_mex_gateway_type_checks_against_the_header():
+    """mex/mmc_hip_mex.cpp cannot be built without MATLAB; compiled against a declaration-only mex.h
+    (tests/mex_stub) every mmc_* call in it is at least checked against include/mmc_hip.h."""
+    import subprocess
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                    "-I", os.path.join(ROOT, "tests", "mex_stub"), "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "mex", "mmc_hip_mex.cpp")], check=True)

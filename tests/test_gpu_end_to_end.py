@@ -195,3 +195,33 @@ def test_full_size_properties():
     assert e1 < 0.9 * e0 and res[-1] < res[0] and st["iterations"] == 200
     assert u.min() >= 0.0 and u.max() <= 1.0 and np.isfinite(w).all()
     s.close()
+
+
+def test_flexbox_framework_presets_start_point_and_block_mean():
+    """framework = 'flexBox' (init_u_flexBox, MultiframeMotionCoupling.m:690-902) on the HIP library:
+    iteration caps 2500 / 800 (:798-802), u starts at the bicubic estimate and w at zero (:893-896),
+    'average' without anti-aliasing is the block mean of superpixelOperator at any zoom (:707-708).
+    Against the oracle started at the same point, zoom 2, forward flow (the direction in which the
+    reference's flexBox terms (:834) and its prost terms (:490-491) state the same model)."""
+    from superresolution_amd.mmc import MultiframeMotionCoupling
+    f, v, _ = make_case(8, 10, 8, 3, factor=2, flow="smooth", flow_scale=1.0)
+    box2 = (lambda x: (np.abs(x) <= 0.5) / 2.0, 2.0)            # two taps of 1/2: the 2x2 block mean
+    P = orc.build_problem(f, v, factor=2, k=KBLUR, flowDirection="forward", interpMethod="custom", interpKernel=box2)
+    iters = 80
+    x0 = np.concatenate([P.u_up.ravel(order="F"), np.zeros(P.M)])
+    x, _, _ = orc.pdhg(P, iters, x=x0)
+    u_ref, w_ref = orc.split_primal(P, x)
+    m = MultiframeMotionCoupling(f, zoom_factor=2, flowField=v, verbose=0)
+    m.framework, m.k, m.flowDirection = "flexBox", KBLUR, "forward"
+    m.init()
+    assert m._opts == {"max_iters": 2500, "tol": 1e-6}
+    assert abs(m.h - P.h) < 1e-5 * P.h
+    u0, w0 = m._solver.get_state()
+    assert np.abs(u0 - P.u_up).max() < 1e-6 and not w0.any()
+    m._opts["max_iters"], m._opts["tol"] = iters, 0.0
+    m.run()
+    assert rel_l2(m.result1, u_ref) < 1e-4 and np.abs(m.result2 - w_ref).max() < 1e-4
+    m.comp_mode = "fast"
+    m.init()
+    assert m._opts == {"max_iters": 800, "tol": 1e-4}
+    m.close()

@@ -39,7 +39,10 @@ CASES = [("bicubic", None, True, KBLUR, 4, 20, 12), ("bicubic", None, False, KBL
          ("nearest", None, False, None, 4, 8, 8), ("nearest", None, True, KBLUR, 2, 10, 14),
          ("lanczos2", None, False, KBLUR, 4, 12, 9), ("lanczos3", None, True, None, 2, 18, 12),
          ("custom", TRI, True, KBLUR, 4, 8, 11), ("average", None, False, KBLUR, 2, 12, 10),
-         ("average", None, False, None, 3, 8, 8)]
+         ("average", None, False, None, 3, 8, 8),
+         # interp1-based samplers (samplingOperator.m:99-106); at zoom 2 the first and last rows use the end formulas
+         ("pchip", None, False, KBLUR, 2, 10, 9), ("pchip", None, False, None, 4, 8, 9),
+         ("bicubic-0", None, False, KBLUR, 4, 9, 8), ("bicubic-0", None, False, None, 2, 10, 12)]
 
 
 @pytest.mark.parametrize("method,kernel,aa,k,factor,ny,nx", CASES)

@@ -55,8 +55,13 @@ def test_init_validates_strings_and_frameworks():
         _obj(comp_mode="fastest", framework="flexBox").init()
     with pytest.raises(RuntimeError, match="prost framework not found"):           # :253-258
         _obj(framework="prost").init()
-    with pytest.raises(RuntimeError, match="Cannot find flexBox framework"):       # :259-263
-        _obj(framework="flexBox").init()
+    with pytest.raises(ValueError, match="Invalid framework string"):               # :236 vs :303-306
+        _obj(framework="flexBox-vector").init()
+    # the flexBox presets run on the HIP library; what init_u_flexBox rejects is rejected first
+    with pytest.raises(ValueError, match="Additive warp and full separation not implemented yet for flexBox"):   # :699-702
+        _obj(framework="flexBox", kappa=float("nan")).init()
+    with pytest.raises(ValueError, match="todo"):                                  # :776-778
+        _obj(framework="flexBox", flowDirection="forward-backward").init()
     with pytest.raises(RuntimeError, match='run the "init" method first'):         # :317-319
         _obj().run()
 
