@@ -176,6 +176,14 @@ int mmc_num_state_frames(const mmc_handle *h);
  * removes the constraint; one NULL is the reference's error (:190-192). */
 int mmc_set_fixed_frame(mmc_handle *h, const float *u0, const float *w0);
 
+/* The temporal rows of the first regulariser as init_u_flexBox writes them for flowDirection
+ * 'backward': {Id, -Wi, Id, -Wi} on [u_i, u_i+1, w_i, w_i+1] (MultiframeMotionCoupling.m:864-868),
+ * i.e. (Id - W)(u + w), where its 'forward' branch (:834) and init_u_prost (:490-491) couple
+ * u - w.  enable != 0 reproduces :864 (a different model: only the sign of w in those rows
+ * changes, the step sizes do not); 0, the default, is the u - w model.  Infimal-convolution
+ * model only.  Takes effect at the next sweep; no mmc_init needed. */
+int mmc_set_flexbox_backward_terms(mmc_handle *h, int enable);
+
 /* Out-of-range / occlusion masks, column sums of the warp, tile source boxes,
  * step sizes and, for a block without neighbours and params.h <= 0, h from its
  * own sums.  A block of a sharded sequence holds only part of those sums: with
@@ -291,6 +299,7 @@ int mmc_group_set_sampling_taps(mmc_group *g, const int32_t *first_y, const floa
 int mmc_group_set_flow(mmc_group *g, const float *v, const uint8_t *occ);
 int mmc_group_set_state(mmc_group *g, const float *u, const float *w);
 int mmc_group_set_fixed_frame(mmc_group *g, const float *u0, const float *w0);
+int mmc_group_set_flexbox_backward_terms(mmc_group *g, int enable);
 int mmc_group_init(mmc_group *g);
 int mmc_group_get_h(const mmc_group *g, float *value);
 int mmc_group_set_h(mmc_group *g, float value);

@@ -436,7 +436,8 @@ class Problem(object):
 
 def build_problem(f_lr, v, factor=4, alpha=0.01, kappa=0.25, flowDirection='backward',
                   k=None, interpMethod='average', interpKernel=None, interpAA=False,
-                  occ=None, u_init=None, w_init=None, h=None, u0_frame=None, w0_frame=None):
+                  occ=None, u_init=None, w_init=None, h=None, u0_frame=None, w0_frame=None,
+                  flexbox_backward_terms=False):
     """init_u_prost restated.  f_lr: ny x nx x nc;  v: Ny x Nx x (nc-1) x 2."""
     f_lr = np.asarray(f_lr, dtype=np.float64)
     ny, nx, nc = f_lr.shape
@@ -489,8 +490,14 @@ def build_problem(f_lr, v, factor=4, alpha=0.01, kappa=0.25, flowDirection='back
         # model (i) / (iv): :480-498, :535-571
         K1 = sp.vstack([W / hh, kappa * G], format='csr')                                # :490
         K2 = sp.vstack([kappa * W / hh, G], format='csr')                                # :492
+        K1w = -K1                                                                        # :490-491
+        if flexbox_backward_terms:
+            # init_u_flexBox, 'backward': temporal row {Id,-Wi,Id,-Wi} = (Id - W)(u + w) on
+            # [u_i,u_i+1,w_i,w_i+1], spatial rows kappa*D on u and -kappa*D on w (:864-866).  The
+            # sign of a whole row does not matter under the norm, the relative sign of w does.
+            K1w = sp.vstack([W / hh, -kappa * G], format='csr')
         rows = [sp.hstack([A, Z(n * nc, M)]),
-                sp.hstack([K1, -K1]),                                                    # :490-491
+                sp.hstack([K1, K1w]),
                 sp.hstack([Z(3 * M, M), K2])]
         P.primal = ['u', 'w']
         P.dual_blocks = [('p', n * nc, 'box_lin', (1.0, fvec)),

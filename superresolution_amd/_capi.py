@@ -71,6 +71,7 @@ SIGNATURES = {
     "mmc_set_state": (C.c_int, [_H, _fp, _fp]),
     "mmc_num_state_frames": (C.c_int, [_H]),
     "mmc_set_fixed_frame": (C.c_int, [_H, _fp, _fp]),
+    "mmc_set_flexbox_backward_terms": (C.c_int, [_H, C.c_int]),
     "mmc_init": (C.c_int, [_H]),
     "mmc_h_partials": (C.c_int, [_H, _dp]),
     "mmc_set_h": (C.c_int, [_H, C.c_float]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     "mmc_group_set_flow": (C.c_int, [_H, _fp, _u8p]),
     "mmc_group_set_state": (C.c_int, [_H, _fp, _fp]),
     "mmc_group_set_fixed_frame": (C.c_int, [_H, _fp, _fp]),
+    "mmc_group_set_flexbox_backward_terms": (C.c_int, [_H, C.c_int]),
     "mmc_group_init": (C.c_int, [_H]),
     "mmc_group_get_h": (C.c_int, [_H, _fp]),
     "mmc_group_set_h": (C.c_int, [_H, C.c_float]),

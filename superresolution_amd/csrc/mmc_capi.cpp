@@ -178,6 +178,7 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
         g.dv_chunk = make_fastdiv((unsigned)(g.chunk > 0 ? g.chunk : 1));
     }
     g.inv_h = 1.f;
+    g.wsgn = -1.f;
 #ifdef MMC_ABLATION
     if (const char *e = getenv("MMC_DEBUG")) g.dbg = atoi(e);
 #endif
@@ -402,6 +403,14 @@ extern "C" int mmc_set_fixed_frame(mmc_handle *h, const float *u0, const float *
     HIPCHK(h, hipMemsetAsync(h->a.q2, 0, B, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->g.fixed = 1;      // only the block that holds frame 0 of the sequence acts on it
+    return MMC_OK;
+}
+
+extern "C" int mmc_set_flexbox_backward_terms(mmc_handle *h, int enable) {
+    REQUIRE_HANDLE(h);
+    if (enable && h->g.model != MODEL_IC)
+        return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_flexbox_backward_terms: only the infimal-convolution model has w (kappa not 1, not NaN)");
+    h->g.wsgn = enable ? 1.f : -1.f;
     return MMC_OK;
 }
 

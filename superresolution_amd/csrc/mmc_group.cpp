@@ -245,6 +245,12 @@ extern "C" int mmc_group_set_fixed_frame(mmc_group *g, const float *u0, const fl
     return MMC_OK;
 }
 
+extern "C" int mmc_group_set_flexbox_backward_terms(mmc_group *g, int enable) {
+    REQUIRE_GROUP(g);
+    for (GroupBlock &b : g->blocks) GBLK(g, b, mmc_set_flexbox_backward_terms(b.h, enable));
+    return MMC_OK;
+}
+
 extern "C" int mmc_group_init(mmc_group *g) {
     REQUIRE_GROUP(g);
     for (GroupBlock &b : g->blocks) GBLK(g, b, mmc_init(b.h));

@@ -71,6 +71,7 @@ struct Geom {
     int chunk;
     FastDiv dv_chunk, dv_per;  // dv_per: chunk * (frames of this launch), set by the launcher
     float alpha, kappa, inv_h;
+    float wsgn;                // sign of w in the temporal rows of K1: -1 (u - w, MultiframeMotionCoupling.m:490-491) or +1 (u + w, :864)
     float radius1, radius2;    // projection radii of the g1 / g2 groups
     // Away from the frame border the column abs-sum of A repeats with period f in both directions.
     // cA_margin > 0: pixels at least that far from every border take it from cA_tab (f = 4 only)

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
                 if (!tp.valid) continue;
                 const float s1 = s1p[j];
                 float s2 = 0.f;
-                if (MODEL == MODEL_IC) s2 = kap * s2p[j] - s1;
+                if (MODEL == MODEL_IC) s2 = kap * s2p[j] + g.wsgn * s1;
                 const double d1 = fx_scaled(s1), d2 = fx_scaled(s2);
                 const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
                 const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
@@ -327,12 +327,12 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
         if (idA) {
             const float s1 = idA1[j];
             Wt1 -= s1;
-            if (MODEL == MODEL_IC) Wt2 -= kap * idA2[j] - s1;
+            if (MODEL == MODEL_IC) Wt2 -= kap * idA2[j] + g.wsgn * s1;
         }
         if (idB) {
             const float s1 = idB1[j];
             Wt1 -= s1;
-            if (MODEL == MODEL_IC) Wt2 -= kap * idB2[j] - s1;
+            if (MODEL == MODEL_IC) Wt2 -= kap * idB2[j] + g.wsgn * s1;
         }
         const float div1 = grad_adj(g, g1x, g1y, r, c, j);
         const float ATp = gather_ATp(g, a.cker, p, r, c);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
             }
             if (idA) {
                 eu[i] -= g.inv_h * sA1[i];
-                if (MODEL == MODEL_IC) ew[i] -= g.inv_h * (kap * sA2[i] - sA1[i]);
+                if (MODEL == MODEL_IC) ew[i] -= g.inv_h * (kap * sA2[i] + g.wsgn * sA1[i]);
             }
         }
     }
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                 Taps tp = make_taps(g, srow, scol, fx, fy);
                 if (!tp.valid) return;
                 const float s1 = f1;
-                const float s2 = (MODEL == MODEL_IC) ? kap * f2 - s1 : 0.f;
+                const float s2 = (MODEL == MODEL_IC) ? kap * f2 + g.wsgn * s1 : 0.f;
                 const double d1 = fx_scaled(s1), d2 = fx_scaled(s2);
                 const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
                 const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                 ld4(s1, FR(a.g1t, t - 1) + j);
                 if (MODEL == MODEL_IC) ld4(s2, FR(a.g2t, t - 1) + j);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { Wt1[i] -= s1[i]; if (MODEL == MODEL_IC) Wt2[i] -= kap * s2[i] - s1[i]; }
+                for (int i = 0; i < 4; ++i) { Wt1[i] -= s1[i]; if (MODEL == MODEL_IC) Wt2[i] -= kap * s2[i] + g.wsgn * s1[i]; }
             }
             // A'p
             float ATp[4];
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) 
         float rs1, rs2 = 0.f;
         if (MODEL == MODEL_IC) {
             // K1 (u - w), K1 = [W/h ; kappa G]  (:490-491);  K2 w, K2 = [kappa W/h ; G]  (:492)
-            k1t = (tu - tw) * g.inv_h;
+            k1t = (tu + g.wsgn * tw) * g.inv_h;
             k1x = kap * ((ux - wx) - (uc - wc));
             k1y = kap * ((uy - wy) - (uc - wc));
             k2t = kap * tw * g.inv_h;
@@ -1130,9 +1130,10 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
             }
             float rs1, rs2 = 0.f;
             if (MODEL == MODEL_IC) {
-                // K1 (u - w), K1 = [W/h ; kappa G]  (:490-491);  K2 w, K2 = [kappa W/h ; G]  (:492)
+                // K1 (u - w), K1 = [W/h ; kappa G]  (:490-491);  K2 w, K2 = [kappa W/h ; G]  (:492);
+                // g.wsgn = +1: temporal row on u + w, the 'backward' terms of init_u_flexBox (:864)
                 const float dc = uc[i] - wc[i];
-                k1t[i] = (tu - tw) * g.inv_h;
+                k1t[i] = (tu + g.wsgn * tw) * g.inv_h;
                 k1x[i] = hasx ? kap * ((ux[i] - wx[i]) - dc) : 0.f;
                 k1y[i] = hasy ? kap * ((uy - wy) - dc) : 0.f;
                 k2t[i] = kap * tw * g.inv_h;

@@ -109,6 +109,7 @@ class MultiframeMotionCoupling(object):
         self._solver = None
         self._opts = {}
         self.check_every = 100
+        self.flexBoxBackwardAsWritten = True     # framework 'flexBox', 'backward': the terms of :864 as they stand
         self.last_stats = None
 
     # ------------------------------------------------------------------
@@ -167,17 +168,22 @@ class MultiframeMotionCoupling(object):
         first nc of the 2nc primal variables are set, :893-896), 'average' without anti-aliasing is
         the block mean of superpixelOperator for every zoom factor (:707-708), additive model and
         'forward-backward' are the reference's errors (:699-702, :776-778).
-        Deviation: the 'backward' branch of the reference couples u + w in its temporal rows
+        The 'backward' branch of the reference couples u + w in its temporal rows
         ({Id,-Wi,Id,-Wi}, :864) where its 'forward' branch (:834) and the prost path (:490-491)
-        couple u - w; this path solves the u - w model for both directions."""
+        couple u - w.  With flexBoxBackwardAsWritten (the default) this path solves what :864
+        states; set it to False for the u - w model in both directions."""
         if isinstance(self.kappa, float) and (math.isnan(self.kappa) or self.kappa == 0):
             raise ValueError("Additive warp and full separation not implemented yet for flexBox.")   # :699-702
         if self.flowDirection == "forward-backward":
             raise ValueError("todo")                                                                  # :776-778
+        if self.kappa == 1:
+            raise MMCError(-4, "init_u_flexBox keeps both variables u and w at kappa = 1 (:805-886); the library's "
+                               "kappa = 1 is the reduced model of init_u_prost (:500-513).  Use framework 'hip'.")
         block_mean = self.interpMethod == "average" and not self.interpAA
-        self._init_u_hip(max_iters=(2500, 800), w_start_zero=True, block_mean=block_mean)
+        as_written = self.flowDirection == "backward" and bool(self.flexBoxBackwardAsWritten)
+        self._init_u_hip(max_iters=(2500, 800), w_start_zero=True, block_mean=block_mean, w_plus=as_written)
 
-    def _init_u_hip(self, max_iters=(7500, 2500), w_start_zero=False, block_mean=False):
+    def _init_u_hip(self, max_iters=(7500, 2500), w_start_zero=False, block_mean=False, w_plus=False):
         """What init_u_prost (:346-574) does, without the sparse matrices."""
         from .solver import FrameBlockSolver
         ny, nx = self._dimsSmall
@@ -229,6 +235,8 @@ class MultiframeMotionCoupling(object):
             if np.isnan(self.kappa) or self.kappa == 1:
                 raise MMCError(-1, "u0_frame/w0_frame need the infimal-convolution model (kappa not 1, not NaN)")
             s.set_fixed_frame(self._u0_frame, self._w0_frame)
+        if w_plus:
+            s.set_flexbox_backward_terms(True)
         s.init()                                                     # masks, h (:431-437), step sizes
         self._h = s.h
         if self.verbose > 0:

@@ -159,6 +159,10 @@ class FrameBlockSolver(object):
                 raise ValueError("fixed frame must be %s" % ((self.Ny, self.Nx),))
         self._check(self._lib.mmc_set_fixed_frame(self._h, fptr(a), fptr(b)))
 
+    def set_flexbox_backward_terms(self, enable=True):
+        """Temporal rows on u + w, as init_u_flexBox writes them for 'backward' (:864)."""
+        self._check(self._lib.mmc_set_flexbox_backward_terms(self._h, int(bool(enable))))
+
     def init(self):
         self._check(self._lib.mmc_init(self._h))
 
@@ -433,6 +437,9 @@ class SequenceGroupSolver(object):
         a = None if u0 is None else as_f32(u0)
         b = None if w0 is None else as_f32(w0)
         self._check(self._lib.mmc_group_set_fixed_frame(self._g, fptr(a), fptr(b)))
+
+    def set_flexbox_backward_terms(self, enable=True):
+        self._check(self._lib.mmc_group_set_flexbox_backward_terms(self._g, int(bool(enable))))
 
     def init(self):
         self._check(self._lib.mmc_group_init(self._g))

@@ -225,3 +225,47 @@ def test_flexbox_framework_presets_start_point_and_block_mean():
     m.init()
     assert m._opts == {"max_iters": 800, "tol": 1e-4}
     m.close()
+
+
+def test_flexbox_backward_terms_as_written():
+    """init_u_flexBox, flowDirection 'backward': the temporal rows {Id,-Wi,Id,-Wi} (:864) couple
+    u + w.  The mirror solves that by default for framework 'flexBox'; the oracle states the same
+    rows (flexbox_backward_terms).  Operators first (K x and K' y against the explicit sparse
+    matrix), then the solve; with the switch off the result is the u - w model's."""
+    from superresolution_amd.mmc import MultiframeMotionCoupling
+    from superresolution_amd.solver import FrameBlockSolver
+    f, v, occ = make_case(12, 9, 8, 3, flow="smooth", flow_scale=1.5, with_occ=True)
+    P = orc.build_problem(f, v, k=KBLUR, occ=occ, flexbox_backward_terms=True)
+    Pm = orc.build_problem(f, v, k=KBLUR, occ=occ)
+    assert abs(P.K - Pm.K).sum() > 1.0 and np.allclose(P.T, Pm.T) and np.allclose(P.S, Pm.S)
+    Ny, Nx, nc = P.dims[:3]
+    M, n = P.M, P.n
+    rng = np.random.default_rng(5)
+    with FrameBlockSolver(9, 8, 4, 3, h=P.h) as s:
+        s.set_lowres(f); s.set_blur(KBLUR); s.set_flow(v, occ); s.set_state(P.u_up, P.u_up)
+        s.set_flexbox_backward_terms(True)
+        s.init()
+        x = rng.normal(size=2 * M)
+        p, g1, g2 = s.debug_apply_K(x[:M].reshape((Ny, Nx, nc), order="F"), x[M:].reshape((Ny, Nx, nc), order="F"))
+        ref = P.K @ x
+        assert rel_l2(g1, ref[n * nc:n * nc + 3 * M]) < 3e-6 and rel_l2(g2, ref[n * nc + 3 * M:]) < 3e-6
+        y = rng.normal(size=P.K.shape[0])
+        y[np.asarray(abs(P.K).sum(axis=1)).ravel() == 0] = 0
+        ku, kw = s.debug_apply_KT(y[:n * nc], y[n * nc:n * nc + 3 * M], y[n * nc + 3 * M:])
+        ref = P.KT @ y
+        assert rel_l2(ku, ref[:M]) < 3e-6 and rel_l2(kw, ref[M:]) < 3e-6
+    iters = 80
+    x0 = np.concatenate([P.u_up.ravel(order="F"), np.zeros(M)])
+    results = {}
+    for as_written, prob in ((True, P), (False, Pm)):
+        x, _, _ = orc.pdhg(prob, iters, x=x0)
+        u_ref, w_ref = orc.split_primal(prob, x)
+        m = MultiframeMotionCoupling(f, flowField=v, occlusion=occ, verbose=0)
+        m.framework, m.k, m.flexBoxBackwardAsWritten = "flexBox", KBLUR, as_written
+        m.init()
+        m._opts["max_iters"], m._opts["tol"] = iters, 0.0
+        m.run()
+        assert rel_l2(m.result1, u_ref) < 1e-4 and np.abs(m.result2 - w_ref).max() < 1e-4
+        results[as_written] = m.result2.copy()
+        m.close()
+    assert np.abs(results[True] - results[False]).max() > 1e-3          # the two models do differ
