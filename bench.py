@@ -89,10 +89,11 @@ def self_launch(args):
 
 
 def cpu_baseline(args, budget_s):
-    """The oracle's PDHG iteration timed on the host cores, on a bounded sample: the first frames
-    of the workload at full frame size with the C/OpenMP restatement (explicit sparse rows for W'
-    and D*B, matrix-free gradient), plus the reference's own quick-start size (600x600x3) in
-    full; or, if the C library cannot be built, a small crop with the scipy.sparse restatement."""
+    """The oracle's PDHG iteration timed on the host cores with the C/OpenMP restatement: the whole
+    single-GPU workload for 50 iterations with stored sparse rows for W' and D*B (the flexBox-style
+    path), a 4-frame sample in the mode that stores no operator, and the reference's own
+    quick-start size (600x600x3) for its 800 iterations; with a budget under 10 s only the 4-frame
+    samples; if the C library cannot be built, a small crop with the scipy.sparse restatement."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from superresolution_amd import synthetic
     try:
@@ -104,17 +105,40 @@ def cpu_baseline(args, budget_s):
     host_cpus = os.cpu_count()
     if have_c:
         ny, nx = args.lr
-        nc = 4
-        blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
-        res = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, budget_s=0.7 * budget_s)
+        lscpu = None
+        try:
+            txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+            cores = [ln.split(":")[1].strip() for ln in txt.splitlines() if ln.startswith(("Core(s) per socket", "Socket(s)"))]
+            lscpu = {"cores_per_socket": int(cores[0]), "sockets": int(cores[1])} if len(cores) == 2 else None
+        except Exception:
+            pass
+        stored = "C/OpenMP restatement with the warp adjoint and D*B stored as sparse rows, the way init_u_flexBox hands " \
+                 "them to flexBox (oracle/mmc_oracle_c.c); loop time only, operator set-up excluded"
+        full = budget_s >= 10.0 and args.frames_per_gpu >= 8
+        if full:
+            # the whole single-GPU workload for 50 iterations (the loop takes about 10 s on 16 threads)
+            nc, iters = args.frames_per_gpu, 50
+            blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
+            res = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, iters=iters)
+            sample = "the whole workload (%dx%dx%d HR) for %d iterations; %s" % (4 * ny, 4 * nx, nc, iters, stored)
+        else:
+            nc = 4
+            blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
+            res = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, budget_s=0.5 * budget_s)
+            sample = "first %d frames of the workload at full size (%dx%dx%d HR), %d iterations; %s" % (
+                nc, 4 * ny, 4 * nx, nc, res["iterations"], stored)
         out = {"value": res["mpx_iter_per_s"], "unit": "HR Mpixel*PDHG-iters/s", "cores": res["threads"],
-               "kind": "port", "host_cpus": host_cpus,
-               "sample": "first %d frames of the workload at full size (%dx%dx%d HR), %d iterations, C/OpenMP restatement "
-                         "with explicit sparse rows for the warp adjoint and D*B (oracle/mmc_oracle_c.c); "
-                         "loop time only, operator set-up excluded"
-                         % (nc, 4 * ny, 4 * nx, nc, res["iterations"])}
+               "kind": "port", "host_cpus": host_cpus, "omp_max_threads": res["threads"], "lscpu": lscpu, "sample": sample,
+               "wall_s_per_sr_frame_at_7500_iters_extrapolated": 7500 * 16 * ny * nx / res["mpx_iter_per_s"] / 1e6}
+        # the same loop without stored operators, on a 4-frame sample
+        blk = synthetic.make_block(ny, nx, 4, 0, 4, device="cpu")
+        r2 = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, budget_s=0.25 * budget_s, matrix_free=True)
+        out["matrix_free"] = {"value": r2["mpx_iter_per_s"], "iterations": r2["iterations"],
+                              "sample": "first 4 frames at full size; taps recomputed, warp adjoint scattered with atomic adds, "
+                                        "D*B through the composite kernel"}
+        # the reference's quick-start size in full: 3 frames of 600x600, 800 iterations (the flexBox cap of 'fast')
         blk = synthetic.make_block(150, 150, 3, 0, 3, device="cpu")
-        r1 = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, budget_s=0.3 * budget_s, max_iters=800)
+        r1 = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, iters=800 if full else None, budget_s=0.25 * budget_s, max_iters=800)
         out["quickstart_600x600x3"] = {"value": r1["mpx_iter_per_s"], "iterations": r1["iterations"],
                                        "seconds_per_800_iterations": 800 * 1.08 / r1["mpx_iter_per_s"]}
         return out

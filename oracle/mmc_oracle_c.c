@@ -15,6 +15,11 @@
  * sizes are those fixed in oracle/mmc_oracle.py (DECISION comments there).
  * float32 arithmetic throughout, double only for the reported sums.
  *
+ * Two modes (mmco_params.matrix_free): 0 stores the operators as sparse rows as above; 1 keeps
+ * nothing but the inputs: taps are recomputed from the flow at every use, W' is a scatter with
+ * atomic float adds (so its sums depend on the thread schedule in the last bits), D*B and its
+ * adjoint are loops over the composite kernel with the replicate border folded in.
+ *
  * Build: see oracle/Makefile (gcc -O3 -fopenmp -shared).
  */
 #include <math.h>
@@ -30,6 +35,7 @@ typedef struct mmco_params {
     int flow_direction;         /* 0 forward 'F-I', 1 backward 'I-F', 2 forward-backward */
     int sampling;               /* 0 'average' (factor 4), 1 'stride' */
     int kh, kw;                 /* blur kernel size, 0 = no blur */
+    int matrix_free;            /* 0: W', A, A' as stored sparse rows; 1: nothing stored, see the header */
 } mmco_params;
 
 typedef struct { int *ptr, *idx; float *val; int rows; } csr;
@@ -100,6 +106,65 @@ static csr build_A(const mmco_params *P, const float *k) {
     return A;
 }
 
+/* Composite kernel of sampling taps (td equal weights from f*R) and the flipped blur: A x (R,C) =
+ * sum_{m,n} ck[m + CH*n] x(clamp(f*R + oy + m), clamp(f*C + ox + n)); one clamp is exact here because
+ * the sampling taps themselves never leave the frame. */
+typedef struct { int CH, CW, oy, ox; float *ck; } composite;
+
+static composite build_composite(const mmco_params *P, const float *k) {
+    const int f = P->factor, td = P->sampling == 0 ? f : 1;
+    const int kh = P->kh > 0 ? P->kh : 1, kw = P->kw > 0 ? P->kw : 1;
+    composite c;
+    int a, b, i, j;
+    c.CH = td + kh - 1; c.CW = td + kw - 1; c.oy = -(kh / 2); c.ox = -(kw / 2);
+    c.ck = (float *)calloc((size_t)c.CH * c.CW, sizeof(float));
+    for (b = 0; b < td; ++b)
+        for (a = 0; a < td; ++a)
+            for (j = 0; j < kw; ++j)
+                for (i = 0; i < kh; ++i)
+                    c.ck[(a + i) + c.CH * (b + j)] += (P->kh > 0 ? k[(kh - 1 - i) + kh * (kw - 1 - j)] : 1.0f) / (float)(td * td);
+    return c;
+}
+
+static float apply_A_mf(const composite *c, int f, int Ny, int Nx, const float *x, int R, int C) {
+    float acc = 0.0f;
+    int m, n;
+    for (n = 0; n < c->CW; ++n) {
+        const int cc = clampi(f * C + c->ox + n, 0, Nx - 1);
+        const float *col = x + (size_t)Ny * cc;
+        for (m = 0; m < c->CH; ++m) acc += c->ck[m + c->CH * n] * col[clampi(f * R + c->oy + m, 0, Ny - 1)];
+    }
+    return acc;
+}
+
+/* (A' p)(r,c) in gather form; a border pixel also collects the taps of the virtual rows / columns
+ * outside the frame that the replicate border folds onto it.  absolute != 0: sum of |weights| (p == NULL). */
+static float apply_AT_mf(const composite *c, int f, int ny, int nx, int Ny, int Nx, const float *p, int r, int col, int absolute) {
+    const int rlo = r == 0 ? (c->oy < 0 ? c->oy : 0) : r, clo = col == 0 ? (c->ox < 0 ? c->ox : 0) : col;
+    int rhi = r, chi = col, rv, cv;
+    float acc = 0.0f;
+    if (r == Ny - 1) { rhi = f * (ny - 1) + c->oy + c->CH - 1; if (rhi < Ny - 1) rhi = Ny - 1; }
+    if (col == Nx - 1) { chi = f * (nx - 1) + c->ox + c->CW - 1; if (chi < Nx - 1) chi = Nx - 1; }
+    for (cv = clo; cv <= chi; ++cv) {
+        const int numc = cv - c->ox - c->CW + 1;
+        int Clo = numc > 0 ? (numc + f - 1) / f : 0, Chi = (cv - c->ox) / f, C;
+        if (Chi > nx - 1) Chi = nx - 1;
+        for (C = Clo; C <= Chi; ++C) {
+            const int nn = cv - f * C - c->ox;
+            for (rv = rlo; rv <= rhi; ++rv) {
+                const int numr = rv - c->oy - c->CH + 1;
+                int Rlo = numr > 0 ? (numr + f - 1) / f : 0, Rhi = (rv - c->oy) / f, R;
+                if (Rhi > ny - 1) Rhi = ny - 1;
+                for (R = Rlo; R <= Rhi; ++R) {
+                    const float wgt = c->ck[(rv - f * R - c->oy) + c->CH * nn];
+                    acc += absolute ? fabsf(wgt) : wgt * p[R + ny * C];
+                }
+            }
+        }
+    }
+    return acc;
+}
+
 typedef struct { int idx[4]; float w[4]; int valid; } taps;
 
 /* bilinear taps of warpingOperator as fixed in oracle/mmc_oracle.py: float32 position arithmetic,
@@ -122,6 +187,16 @@ static taps make_taps(int Ny, int Nx, int r, int c, float vx, float vy) {
 
 static int pair_is_IF(int dir, int q) { return dir == 1 ? 1 : (dir == 0 ? 0 : ((q & 1) == 0)); }
 
+/* taps of pixel j of pair q: stored (tp != NULL) or recomputed from the flow */
+static taps get_taps(const taps *tp, const float *v, const unsigned char *occ, int npairs, int Ny, int Nx, int q, int j) {
+    const size_t N = (size_t)Ny * Nx;
+    taps t;
+    if (tp) return tp[(size_t)q * N + j];
+    t = make_taps(Ny, Nx, j % Ny, j / Ny, v[(size_t)q * N + j], v[(size_t)(npairs + q) * N + j]);
+    if (occ && occ[(size_t)q * N + j]) t.valid = 0;
+    return t;
+}
+
 /* Returns 0 on success.  u, w: start point in, result out (w may be NULL for the models without w).
  * out[0..3] = sum(x+-x)^2, sum(x+)^2, sum(y+-y)^2, sum(y+)^2 of the last iteration, out[4] = h,
  * out[5] = seconds spent in the iteration loop, out[6] = threads used. */
@@ -143,11 +218,19 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
+    const int mf = P->matrix_free != 0;
+    composite ck = build_composite(P, k);
+    float *wt1 = NULL, *wt2 = NULL;
+    memset(&A, 0, sizeof(A)); memset(&AT, 0, sizeof(AT));
+    tp = NULL; WT = NULL;
+    cW = (float *)calloc(M, sizeof(float));
+    cA = (float *)calloc((size_t)N, sizeof(float));
+    sigp = (float *)malloc((size_t)n * sizeof(float));
+    if (!mf) {
     A = build_A(P, k);
     AT = csr_transpose(&A, N);
     tp = (taps *)malloc((size_t)(npairs > 0 ? npairs : 1) * N * sizeof(taps));
     WT = (csr *)calloc((size_t)(npairs > 0 ? npairs : 1), sizeof(csr));
-    cW = (float *)calloc(M, sizeof(float));
     /* constructWarpFF.m:22-38: taps, out-of-range / occlusion marker; W' as sparse rows per pair */
     for (q = 0; q < npairs; ++q) {
         csr Wq;
@@ -176,14 +259,38 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
         csr_free(&Wq);
     }
     /* abs row / column sums of A */
-    cA = (float *)calloc((size_t)N, sizeof(float));
-    sigp = (float *)malloc((size_t)n * sizeof(float));
     {
         int i, e;
         for (i = 0; i < n; ++i) {
             float s = 0.0f;
             for (e = A.ptr[i]; e < A.ptr[i + 1]; ++e) { s += fabsf(A.val[e]); cA[A.idx[e]] += fabsf(A.val[e]); }
             sigp[i] = s > 0.0f ? 1.0f / s : 1.0f;
+        }
+    }
+    } else {
+        /* the same sums without stored operators.  Taps that clamp onto one pixel are summed before the
+         * absolute value is taken, as in the stored rows; with a non-negative composite kernel (block mean
+         * times a non-negative blur) that is the plain sum, which is all this mode supports. */
+        int j, e;
+        for (j = 0; j < ck.CH * ck.CW; ++j) if (ck.ck[j] < 0.0f) { free(ck.ck); free(cW); free(cA); free(sigp); return -2; }
+        wt1 = (float *)malloc(M * sizeof(float));
+        wt2 = (float *)malloc(M * sizeof(float));
+        for (q = 0; q < npairs; ++q) {
+            const int isIF = pair_is_IF(P->flow_direction, q);
+            float *cw_w = cW + (size_t)(isIF ? q + 1 : q) * N, *cw_i = cW + (size_t)(isIF ? q : q + 1) * N;
+            for (j = 0; j < N; ++j) {
+                const taps t = get_taps(NULL, v, occ, npairs, Ny, Nx, q, j);
+                if (!t.valid) continue;
+                for (e = 0; e < 4; ++e) cw_w[t.idx[e]] += t.w[e];
+                cw_i[j] += 1.0f;
+            }
+        }
+#pragma omp parallel for schedule(static)
+        for (jj = 0; jj < (long long)N; ++jj) cA[jj] = apply_AT_mf(&ck, f, ny, nx, Ny, Nx, NULL, (int)(jj % Ny), (int)(jj / Ny), 1);
+        {
+            float s = 0.0f;
+            for (j = 0; j < ck.CH * ck.CW; ++j) s += ck.ck[j];
+            for (j = 0; j < n; ++j) sigp[j] = s > 0.0f ? 1.0f / s : 1.0f;
         }
     }
     ub = (float *)malloc(M * sizeof(float));
@@ -204,8 +311,9 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
             const float *ut = u + (size_t)t * N;
             if (c < Nx - 1) sg += fabs((double)(ut[j + Ny] - ut[j]));
             if (r < Ny - 1) sg += fabs((double)(ut[j + 1] - ut[j]));
-            if (t < npairs && tp[(size_t)t * N + j].valid) {
-                const taps *tt = &tp[(size_t)t * N + j];
+            const taps th = t < npairs ? get_taps(tp, v, occ, npairs, Ny, Nx, t, j) : (taps){{0, 0, 0, 0}, {0, 0, 0, 0}, 0};
+            if (t < npairs && th.valid) {
+                const taps *tt = &th;
                 const int isIF = pair_is_IF(P->flow_direction, t);
                 const float *uw = u + (size_t)(isIF ? t + 1 : t) * N, *ui = u + (size_t)(isIF ? t : t + 1) * N;
                 sw += fabs((double)(tt->w[0] * uw[tt->idx[0]] + tt->w[1] * uw[tt->idx[1]] + tt->w[2] * uw[tt->idx[2]] +
@@ -223,6 +331,29 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
         for (it = 0; it < iters; ++it) {
             const int last = it == iters - 1;
             double a_dx = 0, a_x = 0, a_dy = 0, a_y = 0;
+            if (mf) {
+                /* W' y as a scatter: every unmasked row adds its four taps into the warped frame */
+                memset(wt1, 0, M * sizeof(float));
+                if (model == 0) memset(wt2, 0, M * sizeof(float));
+#pragma omp parallel for schedule(static)
+                for (jj = 0; jj < (long long)npairs * N; ++jj) {
+                    const int qq = (int)(jj / N), j = (int)(jj % N);
+                    const taps t = get_taps(NULL, v, occ, npairs, Ny, Nx, qq, j);
+                    const size_t ow = (size_t)(pair_is_IF(P->flow_direction, qq) ? qq + 1 : qq) * N;
+                    int e;
+                    if (!t.valid) continue;
+                    for (e = 0; e < 4; ++e) {
+                        const float a1 = g1[(size_t)qq * N + j];
+#pragma omp atomic
+                        wt1[ow + t.idx[e]] += t.w[e] * a1;
+                        if (model == 0) {
+                            const float a2 = kap * g2[(size_t)qq * N + j] - a1;
+#pragma omp atomic
+                            wt2[ow + t.idx[e]] += t.w[e] * a2;
+                        }
+                    }
+                }
+            }
             /* primal: x+ = prox_G(x - T K'y), xbar = 2x+ - x */
 #pragma omp parallel for reduction(+ : a_dx, a_x) schedule(static)
             for (jj = 0; jj < (long long)M; ++jj) {
@@ -235,18 +366,26 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                     if (qq < 0 || qq >= npairs) continue;
                     isIF = pair_is_IF(P->flow_direction, qq);
                     if ((qq == t - 1) == isIF) {            /* warp of pair qq samples frame t */
-                        const csr *m = &WT[qq];
+                        const csr *m;
+                        if (mf) continue;                   /* already in wt1 / wt2 */
+                        m = &WT[qq];
                         const float *a1 = g1 + (size_t)qq * N, *a2 = g2 + (size_t)qq * N;
                         for (e = m->ptr[j]; e < m->ptr[j + 1]; ++e) {
                             Wt1 += m->val[e] * a1[m->idx[e]];
                             if (model == 0) Wt2 += m->val[e] * (kap * a2[m->idx[e]] - a1[m->idx[e]]);
                         }
-                    } else if (tp[(size_t)qq * N + j].valid) { /* -Id block of pair qq sits on frame t */
+                    } else if (get_taps(tp, v, occ, npairs, Ny, Nx, qq, j).valid) { /* -Id block of pair qq sits on frame t */
                         Wt1 -= g1[(size_t)qq * N + j];
                         if (model == 0) Wt2 -= kap * g2[(size_t)qq * N + j] - g1[(size_t)qq * N + j];
                     }
                 }
-                for (e = AT.ptr[j]; e < AT.ptr[j + 1]; ++e) ATp += AT.val[e] * p[(size_t)t * n + AT.idx[e]];
+                if (mf) {
+                    Wt1 += wt1[o + j];
+                    Wt2 += wt2[o + j];
+                    ATp = apply_AT_mf(&ck, f, ny, nx, Ny, Nx, p + (size_t)t * n, r, c, 0);
+                } else {
+                    for (e = AT.ptr[j]; e < AT.ptr[j + 1]; ++e) ATp += AT.val[e] * p[(size_t)t * n + AT.idx[e]];
+                }
                 {
                     const float *gx = g1 + M + o, *gy = g1 + 2 * M + o;
                     if (c > 0) div1 += gx[j - Ny];
@@ -287,7 +426,8 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                 const float *x = ub + (size_t)t * N;
                 float acc = 0.0f, po = p[jj], pn;
                 int e;
-                for (e = A.ptr[i]; e < A.ptr[i + 1]; ++e) acc += A.val[e] * x[A.idx[e]];
+                if (mf) acc = apply_A_mf(&ck, f, Ny, Nx, x, i % ny, i / ny);
+                else for (e = A.ptr[i]; e < A.ptr[i + 1]; ++e) acc += A.val[e] * x[A.idx[e]];
                 pn = po + sigp[i] * (acc - f_lr[jj]);
                 pn = pn < -1.0f ? -1.0f : (pn > 1.0f ? 1.0f : pn);
                 p[jj] = pn;
@@ -306,7 +446,8 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                 float n1t, n1x, n1y, o1t = g1[o + j], o1x = g1[M + o + j], o1y = g1[2 * M + o + j], nrm;
                 int valid = 0;
                 if (t < npairs) {
-                    const taps *tt = &tp[o + j];
+                    const taps td_ = get_taps(tp, v, occ, npairs, Ny, Nx, t, j);
+                    const taps *tt = &td_;
                     valid = tt->valid;
                     if (valid) {
                         const int isIF = pair_is_IF(P->flow_direction, t);
@@ -386,8 +527,9 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
         out[6] = 1;
 #endif
     }
-    for (q = 0; q < npairs; ++q) csr_free(&WT[q]);
+    if (WT) for (q = 0; q < npairs; ++q) csr_free(&WT[q]);
     free(WT); free(tp); free(cW); free(cA); free(sigp); free(ub); free(wb); free(p); free(g1); free(g2);
-    csr_free(&A); csr_free(&AT);
+    free(wt1); free(wt2); free(ck.ck);
+    if (!mf) { csr_free(&A); csr_free(&AT); }
     return 0;
 }

@@ -15,7 +15,8 @@ _DIRS = {"forward": 0, "backward": 1, "forward-backward": 2}
 class _Params(C.Structure):
     _fields_ = [("ny", C.c_int), ("nx", C.c_int), ("factor", C.c_int), ("nc", C.c_int),
                 ("alpha", C.c_float), ("kappa", C.c_float), ("h", C.c_float),
-                ("flow_direction", C.c_int), ("sampling", C.c_int), ("kh", C.c_int), ("kw", C.c_int)]
+                ("flow_direction", C.c_int), ("sampling", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("matrix_free", C.c_int)]
 
 
 def build():
@@ -42,14 +43,16 @@ def _lib():
 
 
 def solve(f_lr, v, u0, w0, iters, k=None, factor=4, alpha=0.01, kappa=0.25, flowDirection="backward",
-          sampling="average", occ=None, h=0.0, threads=0):
-    """Runs `iters` PDHG iterations from (u0, w0); returns u, w, info."""
+          sampling="average", occ=None, h=0.0, threads=0, matrix_free=False):
+    """Runs `iters` PDHG iterations from (u0, w0); returns u, w, info.  matrix_free: no stored
+    operators (taps recomputed, W' scattered with atomic adds, D*B as composite-kernel loops)."""
     lib = _lib()
     f32 = lambda a: np.asfortranarray(np.asarray(a), dtype=np.float32)
     f_lr = f32(f_lr)
     ny, nx, nc = f_lr.shape
     Ny, Nx = ny * factor, nx * factor
-    p = _Params(ny, nx, factor, nc, alpha, kappa, h, _DIRS[flowDirection], 0 if sampling == "average" else 1, 0, 0)
+    p = _Params(ny, nx, factor, nc, alpha, kappa, h, _DIRS[flowDirection], 0 if sampling == "average" else 1, 0, 0,
+                1 if matrix_free else 0)
     kk = None
     if k is not None and np.size(k) > 0:
         kk = f32(np.atleast_2d(k))
@@ -70,7 +73,7 @@ def solve(f_lr, v, u0, w0, iters, k=None, factor=4, alpha=0.01, kappa=0.25, flow
     return u, w, info
 
 
-def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0, max_iters=2000):
+def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0, max_iters=2000, matrix_free=False, iters=None):
     """Throughput of the C restatement: iterations sized to roughly fill `budget_s`."""
     import sys
     sys.path.insert(0, HERE)
@@ -79,10 +82,11 @@ def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0, max_iters=2000)
     ny, nx, nc = f_lr.shape
     u_up = np.stack([orc.imresize(f_lr[:, :, i], 4) for i in range(nc)], axis=2)
     M = 16 * ny * nx * nc
-    _, _, probe = solve(f_lr, v, u_up, u_up, 3, k=k, kappa=kappa, threads=threads)
-    per_it = max(probe["loop_seconds"] / 3, 1e-6)
-    iters = int(min(max(budget_s / per_it, 5), max_iters))
+    if iters is None:
+        _, _, probe = solve(f_lr, v, u_up, u_up, 3, k=k, kappa=kappa, threads=threads, matrix_free=matrix_free)
+        per_it = max(probe["loop_seconds"] / 3, 1e-6)
+        iters = int(min(max(budget_s / per_it, 5), max_iters))
     t0 = time.perf_counter()
-    _, _, info = solve(f_lr, v, u_up, u_up, iters, k=k, kappa=kappa, threads=threads)
+    _, _, info = solve(f_lr, v, u_up, u_up, iters, k=k, kappa=kappa, threads=threads, matrix_free=matrix_free)
     return {"mpx_iter_per_s": M * iters / info["loop_seconds"] / 1e6, "iterations": iters,
             "threads": info["threads"], "wall_s": time.perf_counter() - t0}

@@ -39,3 +39,26 @@ def test_c_restatement_variants_and_threads():
     assert np.array_equal(u1, u4) and np.array_equal(w1, w4)       # gather form: no order dependence
     with pytest.raises(RuntimeError):
         occ_c.solve(f, v, P.u_up, P.u_up, 1, k=np.ones((4, 4)))
+
+
+@pytest.mark.parametrize("direction,kappa", [("backward", 0.25), ("forward-backward", 0.25), ("forward", float("nan")), ("backward", 1.0)])
+def test_matrix_free_mode_matches_the_stored_rows(direction, kappa):
+    """The mode that stores no operator (taps recomputed, W' scattered with atomic adds, D*B through
+    the composite kernel with the replicate border folded in) against the sparse oracle and the
+    stored-row mode; its scatter order depends on the thread schedule, hence a tolerance."""
+    f, v, occ = make_case(53, 6, 7, 3, flow="smooth", flow_scale=2.0, with_occ=True)
+    P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
+    x, _, _ = orc.pdhg(P, 60)
+    u_ref, w_ref = orc.split_primal(P, x)
+    u0, w0, i0 = occ_c.solve(f, v, P.u_up, P.u_up, 60, k=KBLUR, kappa=kappa, flowDirection=direction, occ=occ, threads=2)
+    u1, w1, i1 = occ_c.solve(f, v, P.u_up, P.u_up, 60, k=KBLUR, kappa=kappa, flowDirection=direction, occ=occ, threads=3,
+                             matrix_free=True)
+    assert abs(i1["h"] - i0["h"]) < 1e-6 * i0["h"]
+    assert rel_l2(u1, u_ref) < 2e-5 and rel_l2(u1, u0) < 1e-5
+    if w_ref is not None:
+        assert np.abs(w1 - w_ref).max() < 2e-5
+    # 'stride' sampling without blur: a one-tap composite kernel
+    P2 = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, interpMethod="stride")
+    x2, _, _ = orc.pdhg(P2, 30)
+    u2, _, _ = occ_c.solve(f, v, P2.u_up, P2.u_up, 30, kappa=kappa, flowDirection=direction, sampling="stride", matrix_free=True)
+    assert rel_l2(u2, orc.split_primal(P2, x2)[0]) < 2e-5
