@@ -393,6 +393,9 @@ __device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
 #ifndef MMC_SKIP_NOPAIR
 #define MMC_SKIP_NOPAIR 0       // 1: frames without a pair skip their temporal dual planes (measured slower: a wave per SIMD less)
 #endif
+#ifndef MMC_DUAL_UX_LDS
+#define MMC_DUAL_UX_LDS 1       // 1: right neighbour column and the row below of xbar_u come from the staged data-term window
+#endif
 #ifndef MMC_OCC_PRIMAL
 #define MMC_OCC_PRIMAL 1
 #endif
@@ -1022,6 +1025,10 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
     const int j = active ? r + g.Ny * c : 0;
     const bool hasx = c < g.Nx - 1;
 
+    // The data-term window of xbar_u also holds this quad's right neighbour column and the row below it
+    // when the composite kernel reaches at least one pixel beyond the tile on those sides.
+    const bool nb_lds = MMC_DUAL_UX_LDS && VEC && MODE != MODE_STEPS && g.oy <= 0 && g.ox <= 0 &&
+                        g.oy + g.CH - f - 1 >= 0 && g.ox + g.CW - f - 1 >= 0;
     // own loads first; they stay in flight while the window is staged
     float o1t[4], o1x[4], o1y[4], o2t[4], o2x[4], o2y[4], fvx[4], fvy[4];
     float uc[4], ux[4], wc[4] = {0.f, 0.f, 0.f, 0.f}, wx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1029,8 +1036,10 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
     if (active) {
         if (pex) { ld4(fvx, FR(a.vx, t) + j); ld4(fvy, FR(a.vy, t) + j); }
         ld4(uc, ub + j);
-        if (hasx) ld4(ux, ub + j + g.Ny);
-        if (r + 4 < g.Ny) ubelow = ub[j + 4];
+        if (!nb_lds) {
+            if (hasx) ld4(ux, ub + j + g.Ny);
+            if (r + 4 < g.Ny) ubelow = ub[j + 4];
+        }
         if (MODEL == MODEL_IC) {
             ld4(wc, wb + j);
             if (hasx) ld4(wx, wb + j + g.Ny);
@@ -1098,6 +1107,11 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
     if (MODE != MODE_STEPS) __syncthreads();
 
     float part[2] = {0.f, 0.f};
+    if (active && nb_lds) {
+        const float *own = ubl + (4 * rq - g.oy + wpad) + SR * (lc - g.ox);
+        if (hasx) ld4(ux, own + SR);
+        if (r + 4 < g.Ny) ubelow = own[4];
+    }
     if (active) {
         float k1t[4], k1x[4], k1y[4], k2t[4], k2x[4], k2y[4], sg1[4], sg2[4];
         bool valid[4];
