@@ -325,7 +325,8 @@ def main():
                                    % (nc, Ny, Nx, ny, nx, L, "infimal-convolution" if model == "ic" else "single-primal",
                                       args.kappa, args.flow),
                        "frames_total": nc, "hr_pixels_total": M_total, "parallelism": "frame-block x%d" % world,
-                       "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None},
+                       "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
+                       "plane_skew_bytes": s.plane_skew},
             "wall_s_per_sr_frame_at_7500_iters": wall / args.steps * 7500 / nc,
             "iteration_roofline": {"bytes_per_px_iter": BYTES_ITER[model],
                                    "achieved_GBps_per_gpu": BYTES_ITER[model] * M_total * args.steps / wall / world / 1e9,

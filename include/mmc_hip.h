@@ -24,6 +24,7 @@
 #ifndef MMC_HIP_H
 #define MMC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -328,6 +329,12 @@ int mmc_debug_steps(mmc_handle *h, float *tau_u, float *tau_w,
  * not from the plane that mmc_init wrote (which mmc_debug_steps reads).  Both must agree
  * bit for bit. */
 int mmc_debug_steps_update(mmc_handle *h, float *tau_u, float *tau_w);
+
+/* Placement of the per-pixel planes in device memory: plane i starts i * (this many bytes) into its
+ * allocation, so that the planes a sweep streams through together do not all sit at the same address
+ * modulo a power of two.  mmc_create picks the value for large blocks by timing a streaming probe.
+ * Results do not depend on it. */
+size_t mmc_debug_plane_skew(const mmc_handle *h);
 
 #ifdef __cplusplus
 }

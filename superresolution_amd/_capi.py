@@ -112,6 +112,7 @@ SIGNATURES = {
     "mmc_debug_apply_KT": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "mmc_debug_steps": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),
     "mmc_debug_steps_update": (C.c_int, [_H, _fp, _fp]),
+    "mmc_debug_plane_skew": (C.c_size_t, [_H]),
 }
 
 _lib = None

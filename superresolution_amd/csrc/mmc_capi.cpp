@@ -39,6 +39,7 @@ struct mmc_handle {
     size_t ovf_capacity = 0;                 // entries allocated for a.ovf_idx
     size_t ovf_total = 0;                    // entries in use
     std::string err;
+    size_t plane_skew = 0;                   // bytes between the starts of consecutive per-pixel planes modulo their allocation alignment
     bool profiling = false;
     std::vector<hipEvent_t> events;       // 4 per profiled iteration
     double prof_ms[3] = {0, 0, 0};
@@ -75,16 +76,30 @@ int mmc_static_fail(int code, const char *literal) {
 
 static size_t frame_slots(const mmc_handle *h) { return (size_t)h->L + 2; }
 
+// `skew` bytes (a multiple of 256) are left unused in front of the array, see PLANE_SKEW.
 template <typename T>
-static int dev_alloc(mmc_handle *h, T **ptr, size_t count, bool zero = true) {
+static int dev_alloc(mmc_handle *h, T **ptr, size_t count, bool zero = true, size_t skew = 0) {
     void *p = nullptr;
     size_t bytes = (count ? count : 1) * sizeof(T);
-    HIPCHK(h, hipMalloc(&p, bytes));
+    HIPCHK(h, hipMalloc(&p, bytes + skew));
     h->allocs.push_back(p);
+    p = static_cast<char *>(p) + skew;
     if (zero) HIPCHK(h, hipMemsetAsync(p, 0, bytes, h->stream));
     *ptr = (T *)p;
     return MMC_OK;
 }
+
+// Large allocations come back aligned to 2 MiB, so the per-pixel planes would all start at the same
+// address modulo any power of two.  A sweep streams through ten or more of them at the same offset,
+// and on MI355X planes whose distance is a multiple of 256 KiB move measurably slower
+// (tools/stream_bench8.hip: 10 read streams, 6 written back: 5.25 TB/s, against 5.49 TB/s with the
+// planes 320 KiB further apart each).  Which distance is best depends on the frame size (it acts
+// together with the distance between the ranges the eight XCD classes walk), so plane i is shifted
+// by i * skew inside its allocation and mmc_create picks the skew for large blocks by timing a
+// streaming probe of the sweeps' access pattern over the still empty planes.
+enum : size_t { PLANE_SKEW_DEFAULT = 320u << 10, PLANE_SKEW_MAX = 1u << 20, PLANE_SLOTS = 16 };
+static const size_t kSkewCandidates[] = {320u << 10, 84u << 10, 196u << 10, 148u << 10, 456u << 10, 672u << 10, 980u << 10, 44u << 10,
+                                         20u << 10, 116u << 10, 244u << 10, 388u << 10};
 
 extern "C" int mmc_abi_version(void) { return MMC_ABI_VERSION; }
 
@@ -92,6 +107,46 @@ extern "C" const char *mmc_last_error(const mmc_handle *h) {
     if (h) return h->err.c_str();
     return g_static_err ? g_static_err : g_create_err.c_str();
 }
+
+// Picks the shift between consecutive planes (see PLANE_SKEW_DEFAULT).  Blocks of at least 4 MiB per
+// plane whose frames take the row-quad sweeps are probed: each candidate is timed with one dual-like
+// and one primal-like pass of the streaming probe over the (zeroed) planes, best of two.
+static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, size_t *skew) {
+    const Geom &g = h->g;
+#ifdef MMC_ABLATION
+    if (const char *e = getenv("MMC_PLANE_SKEW")) { *skew = std::min((size_t)atol(e) & ~(size_t)255, (size_t)PLANE_SKEW_MAX); return MMC_OK; }
+#endif
+    const size_t plane_bytes = frame_slots(h) * (size_t)g.N * sizeof(float);
+    if (plane_bytes < ((size_t)4 << 20) || g.Ny % 4 != 0 || raw.size() < 12) return MMC_OK;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    float best = 0.f;
+    int rc = MMC_OK;
+    for (size_t cand : kSkewCandidates) {
+        float *pl[12];
+        for (int i = 0; i < 12; ++i) pl[i] = raw[(size_t)i] + (size_t)i * cand / sizeof(float);
+        float tbest = 0.f;
+        for (int rep = 0; rep < 3 && rc == MMC_OK; ++rep) {          // the first repetition warms up
+            hipError_t e = hipEventRecord(e0, h->stream);
+            if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, h->L, true, h->stream);
+            if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, h->L, false, h->stream);
+            if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) { rc = fail(h, MMC_ERR_HIP, std::string("plane placement probe: ") + hipGetErrorString(e)); break; }
+            if (rep > 0 && (tbest == 0.f || ms < tbest)) tbest = ms;
+        }
+        if (rc != MMC_OK) break;
+        if (best == 0.f || tbest < best) { best = tbest; *skew = cand; }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}
+
+extern "C" size_t mmc_debug_plane_skew(const mmc_handle *h) { return h ? h->plane_skew : 0; }
 
 extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     if (!p || !out) return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: null argument");
@@ -188,14 +243,23 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     memset(&a, 0, sizeof(a));
     const size_t fs = frame_slots(h) * (size_t)g.N;
     float **per_px[] = {&a.u, &a.w, &a.ub, &a.wb, &a.g1t, &a.g1x, &a.g1y, &a.g2t, &a.g2x, &a.g2y, &a.vx, &a.vy, &a.cW};
-    for (float **pp : per_px) {
-        int rc = dev_alloc(h, pp, fs);
-        if (rc != MMC_OK) return bail(rc);
-    }
     int rc;
-    if ((rc = dev_alloc(h, &a.idq, (size_t)h->L * ((size_t)g.N / 4 + 1))) != MMC_OK) return bail(rc);
-    if ((rc = dev_alloc(h, &a.p, (size_t)h->L * g.n)) != MMC_OK) return bail(rc);
-    if ((rc = dev_alloc(h, &a.f, (size_t)h->L * g.n)) != MMC_OK) return bail(rc);
+    {
+        // every plane gets room for the largest shift; the shifts are chosen below
+        const size_t room = (PLANE_SLOTS - 1) * PLANE_SKEW_MAX / sizeof(float);
+        std::vector<float *> raw;
+        for (float **pp : per_px) {
+            if ((rc = dev_alloc(h, pp, fs + room)) != MMC_OK) return bail(rc);
+            raw.push_back(*pp);
+        }
+        size_t skew = PLANE_SKEW_DEFAULT;
+        if ((rc = choose_plane_skew(h, raw, &skew)) != MMC_OK) return bail(rc);
+        h->plane_skew = skew;
+        for (size_t i = 0; i < raw.size(); ++i) *per_px[i] = raw[i] + i * skew / sizeof(float);
+    }
+    if ((rc = dev_alloc(h, &a.idq, (size_t)h->L * ((size_t)g.N / 4 + 1), true, 13 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.p, (size_t)h->L * g.n, true, 14 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.f, (size_t)h->L * g.n, true, 15 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.cA, (size_t)g.N)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.sigp, (size_t)g.n)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);

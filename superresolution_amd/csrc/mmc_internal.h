@@ -133,6 +133,9 @@ struct BicubicTab { float w[MMC_BICUBIC_MAX_ZOOM][MMC_BICUBIC_TAPS]; int first[M
 // u, ub (and w, wb when the model has w) of the local frames <- imresize(f, zoom, 'bicubic')
 hipError_t mmc_launch_bicubic_start(const Geom &g, const Arrays &a, const BicubicTab &tab, hipStream_t s);
 hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s);
+// Streams through 12 per-pixel planes (L+2 frame slots each) with the block walk and access shape of
+// the sweeps and leaves their contents unchanged; times how a placement of the planes performs.
+hipError_t mmc_launch_stream_probe(const Geom &g, float *const planes[12], int nf, bool dual_like, hipStream_t s);
 
 // Failure of an entry point that has no handle and must not allocate: `literal` (a string literal)
 // becomes what mmc_last_error(NULL) returns on this thread; returns `code`.

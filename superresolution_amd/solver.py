@@ -289,6 +289,11 @@ class FrameBlockSolver(object):
         self._check(self._lib.mmc_debug_steps(self._h, fptr(tu), fptr(tw), fptr(sp), fptr(s1), fptr(s2)))
         return tu, tw, sp, s1, s2
 
+    @property
+    def plane_skew(self):
+        """Bytes by which consecutive per-pixel planes are shifted against each other (placement only)."""
+        return int(self._lib.mmc_debug_plane_skew(self._h))
+
     def debug_steps_update(self):
         """tau_u, tau_w as the update sweep derives them (see mmc_debug_steps_update)."""
         N, L = self.Ny * self.Nx, self.L
