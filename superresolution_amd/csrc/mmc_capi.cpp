@@ -98,8 +98,7 @@ static int dev_alloc(mmc_handle *h, T **ptr, size_t count, bool zero = true, siz
 // by i * skew inside its allocation and mmc_create picks the skew for large blocks by timing a
 // streaming probe of the sweeps' access pattern over the still empty planes.
 enum : size_t { PLANE_SKEW_DEFAULT = 320u << 10, PLANE_SKEW_MAX = 1u << 20, PLANE_SLOTS = 16 };
-static const size_t kSkewCandidates[] = {320u << 10, 84u << 10, 196u << 10, 148u << 10, 456u << 10, 672u << 10, 980u << 10, 44u << 10,
-                                         20u << 10, 116u << 10, 244u << 10, 388u << 10};
+enum { PLANE_SKEW_STEPS = 16, PLANE_PROBE_FRAMES = 12 };      // candidates 44 KiB + k * 32 KiB, k < 16
 
 extern "C" int mmc_abi_version(void) { return MMC_ABI_VERSION; }
 
@@ -110,7 +109,7 @@ extern "C" const char *mmc_last_error(const mmc_handle *h) {
 
 // Picks the shift between consecutive planes (see PLANE_SKEW_DEFAULT).  Blocks of at least 4 MiB per
 // plane whose frames take the row-quad sweeps are probed: each candidate is timed with one dual-like
-// and one primal-like pass of the streaming probe over the (zeroed) planes, best of two.
+// and one primal-like pass of the streaming probe over the first frames of the (zeroed) planes, best of two.
 static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, size_t *skew) {
     const Geom &g = h->g;
 #ifdef MMC_ABLATION
@@ -123,14 +122,16 @@ static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, siz
     HIPCHK(h, hipEventCreate(&e1));
     float best = 0.f;
     int rc = MMC_OK;
-    for (size_t cand : kSkewCandidates) {
+    const int nfp = std::min(h->L, (int)PLANE_PROBE_FRAMES);
+    for (int kc = 0; kc < PLANE_SKEW_STEPS; ++kc) {
+        const size_t cand = ((size_t)44 << 10) + (size_t)kc * ((size_t)32 << 10);
         float *pl[12];
         for (int i = 0; i < 12; ++i) pl[i] = raw[(size_t)i] + (size_t)i * cand / sizeof(float);
         float tbest = 0.f;
         for (int rep = 0; rep < 3 && rc == MMC_OK; ++rep) {          // the first repetition warms up
             hipError_t e = hipEventRecord(e0, h->stream);
-            if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, h->L, true, h->stream);
-            if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, h->L, false, h->stream);
+            if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, nfp, true, h->stream);
+            if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, nfp, false, h->stream);
             if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
             float ms = 0.f;
