@@ -98,7 +98,9 @@ static int dev_alloc(mmc_handle *h, T **ptr, size_t count, bool zero = true, siz
 // by i * skew inside its allocation and mmc_create picks the skew for large blocks by timing a
 // streaming probe of the sweeps' access pattern over the still empty planes.
 enum : size_t { PLANE_SKEW_DEFAULT = 320u << 10, PLANE_SKEW_MAX = 1u << 20, PLANE_SLOTS = 16 };
-enum { PLANE_SKEW_STEPS = 16, PLANE_PROBE_FRAMES = 12 };      // candidates 44 KiB + k * 32 KiB, k < 16
+// candidates 64 KiB + k * 32 KiB, k < 16; k = 8 is the default
+enum { PLANE_SKEW_STEPS = 16, PLANE_SKEW_DEFAULT_STEP = 8, PLANE_PROBE_FRAMES = 12, PLANE_PROBE_ROUNDS = 6 };
+static const float PLANE_PROBE_WARM_MS = 40.f, PLANE_PROBE_MARGIN = 0.985f;
 
 extern "C" int mmc_abi_version(void) { return MMC_ABI_VERSION; }
 
@@ -107,40 +109,68 @@ extern "C" const char *mmc_last_error(const mmc_handle *h) {
     return g_static_err ? g_static_err : g_create_err.c_str();
 }
 
-// Picks the shift between consecutive planes (see PLANE_SKEW_DEFAULT).  Blocks of at least 4 MiB per
-// plane whose frames take the row-quad sweeps are probed: each candidate is timed with one dual-like
-// and one primal-like pass of the streaming probe over the first frames of the (zeroed) planes, best of two.
+// Picks the shift between consecutive planes (see PLANE_SKEW_DEFAULT).  Blocks of at least 64 MiB per
+// plane (on smaller ones the timings scatter more than the shifts differ) whose frames take the row-quad sweeps are probed: each candidate is timed with one dual-like
+// and one primal-like pass of the streaming probe over the first frames of the (zeroed) planes.
+// The clocks of an idle GPU settle only after some milliseconds of load and single timings scatter by
+// about as much as neighbouring candidates differ, so the probe first runs untimed for a while, then
+// times every candidate PLANE_PROBE_ROUNDS times in alternating order, keeps the minimum of each and
+// takes the best 1-2-1 weighted mean over neighbouring candidates (the response is smooth in the shift).
+// The probe ranks shifts as the sweeps do where they differ by several per cent (2160-row frames);
+// differences of about one per cent between its timings do not carry over to the sweeps (1080-row
+// frames: the default is the sweeps' optimum, the probe is flat), so the default stays unless a
+// candidate beats it by PLANE_PROBE_MARGIN.
+static_assert(((size_t)64 << 10) + PLANE_SKEW_DEFAULT_STEP * ((size_t)32 << 10) == PLANE_SKEW_DEFAULT, "default shift must be a probe candidate");
 static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, size_t *skew) {
     const Geom &g = h->g;
-#ifdef MMC_ABLATION
+    // tuning override: MMC_PLANE_SKEW=<bytes> fixes the shift, MMC_PROBE_TRACE=1 prints the probe's timings
     if (const char *e = getenv("MMC_PLANE_SKEW")) { *skew = std::min((size_t)atol(e) & ~(size_t)255, (size_t)PLANE_SKEW_MAX); return MMC_OK; }
-#endif
     const size_t plane_bytes = frame_slots(h) * (size_t)g.N * sizeof(float);
-    if (plane_bytes < ((size_t)4 << 20) || g.Ny % 4 != 0 || raw.size() < 12) return MMC_OK;
+    if (plane_bytes < ((size_t)64 << 20) || g.Ny % 4 != 0 || raw.size() < 12) return MMC_OK;
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
-    float best = 0.f;
     int rc = MMC_OK;
     const int nfp = std::min(h->L, (int)PLANE_PROBE_FRAMES);
-    for (int kc = 0; kc < PLANE_SKEW_STEPS; ++kc) {
-        const size_t cand = ((size_t)44 << 10) + (size_t)kc * ((size_t)32 << 10);
+    float tmin[PLANE_SKEW_STEPS];
+    for (float &t : tmin) t = 0.f;
+    auto cand_of = [](int kc) { return ((size_t)64 << 10) + (size_t)kc * ((size_t)32 << 10); };
+    auto pass = [&](int kc, float *ms) -> hipError_t {
         float *pl[12];
-        for (int i = 0; i < 12; ++i) pl[i] = raw[(size_t)i] + (size_t)i * cand / sizeof(float);
-        float tbest = 0.f;
-        for (int rep = 0; rep < 3 && rc == MMC_OK; ++rep) {          // the first repetition warms up
-            hipError_t e = hipEventRecord(e0, h->stream);
-            if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, nfp, true, h->stream);
-            if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, nfp, false, h->stream);
-            if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
-            if (e == hipSuccess) e = hipEventSynchronize(e1);
-            float ms = 0.f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-            if (e != hipSuccess) { rc = fail(h, MMC_ERR_HIP, std::string("plane placement probe: ") + hipGetErrorString(e)); break; }
-            if (rep > 0 && (tbest == 0.f || ms < tbest)) tbest = ms;
+        for (int i = 0; i < 12; ++i) pl[i] = raw[(size_t)i] + (size_t)i * cand_of(kc) / sizeof(float);
+        hipError_t e = hipEventRecord(e0, h->stream);
+        if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, nfp, true, h->stream);
+        if (e == hipSuccess) e = mmc_launch_stream_probe(g, pl, nfp, false, h->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+        return e;
+    };
+    hipError_t e = hipSuccess;
+    float ms = 0.f, warm = 0.f;
+    for (int i = 0; i < 400 && warm < PLANE_PROBE_WARM_MS && e == hipSuccess; ++i) { e = pass(i % PLANE_SKEW_STEPS, &ms); warm += ms; }
+    for (int round = 0; round < PLANE_PROBE_ROUNDS && e == hipSuccess; ++round)
+        for (int i = 0; i < PLANE_SKEW_STEPS && e == hipSuccess; ++i) {
+            const int kc = (round & 1) ? PLANE_SKEW_STEPS - 1 - i : i;
+            e = pass(kc, &ms);
+            if (e == hipSuccess && (tmin[kc] == 0.f || ms < tmin[kc])) tmin[kc] = ms;
         }
-        if (rc != MMC_OK) break;
-        if (best == 0.f || tbest < best) { best = tbest; *skew = cand; }
+    if (e != hipSuccess) rc = fail(h, MMC_ERR_HIP, std::string("plane placement probe: ") + hipGetErrorString(e));
+    else {
+        float best = 0.f, tdef = 0.f;
+        int kbest = PLANE_SKEW_DEFAULT_STEP;
+        for (int kc = 0; kc < PLANE_SKEW_STEPS; ++kc) {
+            const float lo = tmin[kc > 0 ? kc - 1 : kc], hi = tmin[kc + 1 < PLANE_SKEW_STEPS ? kc + 1 : kc];
+            const float t = 0.25f * lo + 0.5f * tmin[kc] + 0.25f * hi;
+            if (kc == PLANE_SKEW_DEFAULT_STEP) tdef = t;
+            if (best == 0.f || t < best) { best = t; kbest = kc; }
+        }
+        *skew = cand_of(best < PLANE_PROBE_MARGIN * tdef ? kbest : PLANE_SKEW_DEFAULT_STEP);
+        if (getenv("MMC_PROBE_TRACE")) {
+            fprintf(stderr, "plane shift probe (%d frames, warm %.1f ms):", nfp, warm);
+            for (int kc = 0; kc < PLANE_SKEW_STEPS; ++kc) fprintf(stderr, " %zu:%.4f", cand_of(kc) >> 10, tmin[kc]);
+            fprintf(stderr, " -> %zu\n", *skew);
+        }
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);

@@ -1637,45 +1637,59 @@ __global__ __launch_bounds__(MMC_THREADS) void k_bicubic_start(Geom g, Arrays a,
 }
 
 // Streaming probe for the placement of the per-pixel planes (see mmc_launch_stream_probe): the
-// block walk and the row-quad access pattern of the sweeps without their arithmetic.  Every quad
-// reads NRD planes and writes what it read back to the first NWR of them, so the contents of the
-// planes do not change.
+// block walk and the row-quad access pattern of the sweeps without their arithmetic, over planes in
+// allocation order u, w, ub, wb, g1t, g1x, g1y, g2t, g2x, g2y, vx, vy.  The primal-like pass reads
+// u, w, the six duals and the flow, reads the temporal duals of the previous frame a second time (as
+// the scatter does) and writes u, w, ub, wb; the dual-like pass reads ub, wb, the duals and the flow,
+// ub and wb of the next frame (as the warp taps do) and writes the duals.  Planes that are read get
+// their own values back, ub and wb of the primal-like pass the value 0: the planes are all zero
+// when the probe runs and stay so.
 struct ProbePlanes { float *p[12]; };
-template <int NRD, int NWR>
-__global__ __launch_bounds__(MMC_THREADS) void k_stream_probe(Geom g, ProbePlanes a, int nf, int reverse) {
+template <bool DUAL>
+__global__ __launch_bounds__(MMC_THREADS) void k_stream_probe(Geom g, ProbePlanes a, int nf) {
     int tile, trel;
-    if (!decode_block(g, nf, tile, trel, reverse != 0)) return;
+    if (!decode_block(g, nf, tile, trel, DUAL)) return;
     const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
     const int rq = threadIdx.x & (TILE_R / 4 - 1), lc = threadIdx.x / (TILE_R / 4);
     const int r = tr * TILE_R + 4 * rq, c = tc * TILE_C + lc;
     if (r >= g.Ny || c >= g.Nx) return;
     const size_t j = (size_t)(trel + 1) * (size_t)g.N + (size_t)r + (size_t)g.Ny * c;
-    float4 v[NRD];
+    float4 v[12];
 #pragma unroll
-    for (int i = 0; i < NRD; ++i) v[i] = *reinterpret_cast<const float4 *>(a.p[i] + j);
-    float s = 0.f;
+    for (int i = 0; i < 12; ++i) {
+        const bool rd = DUAL ? i >= 2 : (i < 2 || i >= 4);
+        v[i] = rd ? *reinterpret_cast<const float4 *>(a.p[i] + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // second use of a neighbouring frame's planes (ghost slots exist on both sides)
+    const size_t j2 = DUAL ? j + (size_t)g.N : j - (size_t)g.N;
+    const float4 x0 = *reinterpret_cast<const float4 *>(a.p[DUAL ? 2 : 4] + j2);
+    const float4 x1 = *reinterpret_cast<const float4 *>(a.p[DUAL ? 3 : 7] + j2);
+    float s = x0.x + x0.y + x0.z + x0.w + x1.x + x1.y + x1.z + x1.w;
 #pragma unroll
-    for (int i = NWR; i < NRD; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    for (int i = 0; i < 12; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
     // data dependence of the stores on every load (s is finite for finite planes, so this adds exactly 0)
     const float z = (s != s) ? 1.f : 0.f;
 #pragma unroll
-    for (int i = 0; i < NWR; ++i) {
-        v[i].x += z;
-        *reinterpret_cast<float4 *>(a.p[i] + j) = v[i];
+    for (int i = 0; i < 12; ++i) {
+        const bool wr = DUAL ? (i >= 4 && i < 10) : i < 4;
+        if (wr) {
+            v[i].x += z;
+            *reinterpret_cast<float4 *>(a.p[i] + j) = v[i];
+        }
     }
 }
 
-// One launch of the probe over local frames [0, nf): a dual-like mix (10 planes read, 6 written
-// back in place) walked backwards when `dual_like`, else a primal-like one (12 read, 4 written) walked
-// forwards.  Needs Ny % 4 == 0.
+// One launch of the probe over local frames [0, nf): the dual-like pass walks the block sequence
+// backwards like the dual sweep, the primal-like one forwards.  Needs Ny % 4 == 0 and planes of at
+// least nf + 2 frames.
 hipError_t mmc_launch_stream_probe(const Geom &g0, float *const planes[12], int nf, bool dual_like, hipStream_t s) {
     Geom g = g0;
     g.dv_per = make_fastdiv((unsigned)((g.chunk > 0 ? g.chunk : 1) * nf));
     ProbePlanes a;
     for (int i = 0; i < 12; ++i) a.p[i] = planes[i];
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
-    if (dual_like) hipLaunchKernelGGL((k_stream_probe<10, 6>), grid, block, 0, s, g, a, nf, 1);
-    else hipLaunchKernelGGL((k_stream_probe<12, 4>), grid, block, 0, s, g, a, nf, 0);
+    if (dual_like) hipLaunchKernelGGL((k_stream_probe<true>), grid, block, 0, s, g, a, nf);
+    else hipLaunchKernelGGL((k_stream_probe<false>), grid, block, 0, s, g, a, nf);
     return hipGetLastError();
 }
 
