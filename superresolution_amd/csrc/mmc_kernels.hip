@@ -1707,6 +1707,17 @@ static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int 
     else hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
 }
 
+// -DMMC_TUNE_LDS_PAD: env MMC_LDS_PAD = bytes of unused LDS added to every sweep launch, which lowers the
+// number of workgroups a CU holds (occupancy experiments); a regular build adds nothing.
+static size_t lds_pad() {
+#ifdef MMC_TUNE_LDS_PAD
+    static const size_t pad = getenv("MMC_LDS_PAD") ? (size_t)atol(getenv("MMC_LDS_PAD")) : 0;
+    return pad;
+#else
+    return 0;
+#endif
+}
+
 // The block decode divides by chunk * (frames of the launch); the magic number goes in with the launch.
 static Geom with_launch_frames(const Geom &g0, int nf) {
     Geom g = g0;
@@ -1718,7 +1729,7 @@ template <int MODEL, int F>
 static void launch_primal4_m(const Geom &g0, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     const Geom g = with_launch_frames(g0, nf);
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
-    const size_t lds = (size_t)(6 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float);
+    const size_t lds = (size_t)(6 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float) + lds_pad();
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS_UPD) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS_UPD, false, F>), grid, block, lds, s, g, a, t0, nf);
@@ -1767,7 +1778,7 @@ static void launch_dual4_m(const Geom &g0, const Arrays &a, int t0, int nf, int 
     const int f = g.f;
     const int SRmax = g.SRp > TILE_R + g.CH - f ? g.SRp : TILE_R + g.CH - f;
     const size_t lds = (size_t)(((SRmax * (TILE_C + g.CW - f) + 3) & ~3) + (((MMC_THREADS / 64) * (TILE_R / f) * (TILE_C / f) + 3) & ~3) +
-                                g.MPq * g.CW + 2 * MMC_WARP_MAX) * sizeof(float);
+                                g.MPq * g.CW + 2 * MMC_WARP_MAX) * sizeof(float) + lds_pad();
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F>), grid, block, lds, s, g, a, t0, nf);
