@@ -158,6 +158,25 @@ def test_runs_are_bitwise_reproducible():
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_results_do_not_depend_on_the_plane_placement(monkeypatch):
+    """The per-pixel planes are shifted against each other inside their allocations (a tuning choice,
+    MMC_PLANE_SKEW fixes it): every shift must give bit-for-bit the same iterates."""
+    from superresolution_amd.solver import FrameBlockSolver
+    f, v, occ = make_case(15, 16, 20, 4, flow="random", flow_scale=2.0)
+    P = orc.build_problem(f, v, k=KBLUR)
+    outs = []
+    for skew in ("0", "256", "45056", "327680", "1048576"):
+        monkeypatch.setenv("MMC_PLANE_SKEW", skew)
+        with FrameBlockSolver(16, 20, 4, 4, h=P.h) as s:
+            assert s.plane_skew == int(skew)
+            s.set_lowres(f); s.set_blur(KBLUR); s.set_flow(v); s.set_state(P.u_up, P.u_up); s.init()
+            s.solve(40)
+            outs.append(s.get_state())
+    for u, w in outs[1:]:
+        assert np.array_equal(u, outs[0][0]) and np.array_equal(w, outs[0][1])
+    assert rel_l2(outs[0][0], orc.split_primal(P, orc.pdhg(P, 40)[0])[0]) < 1e-4
+
+
 def test_full_size_properties():
     """Benchmark size (1080x1920 HR, here 6 frames): properties that need no oracle run --
     adjointness <Kx,y> = <x,K'y> of the device operators, energy decrease, residual
