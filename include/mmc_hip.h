@@ -336,6 +336,57 @@ int mmc_debug_steps_update(mmc_handle *h, float *tau_u, float *tau_w);
  * Results do not depend on it. */
 size_t mmc_debug_plane_skew(const mmc_handle *h);
 
+/* ---- Classical single-frame super-resolution (the reference's comparison methods) ------------
+ * classical methods/singleframeMotionSR_mitzel_prost.m, ..._mitzel_prost_fast.m and
+ * ..._unger_prost.m assemble, after their flow estimation (which stays on the reference path),
+ * one problem for prost.solve (..._mitzel_prost.m:82-172):
+ *     min_u  sum_i H_delta(D B W_i u - f_i) + alpha TV(u)
+ * u: the central high-resolution frame (N = Ny*Nx); f_i: low-resolution frame i; W_i: bilinear
+ * warp with the flow from the central frame to frame i (:64-70); D the box sampler of :75-77
+ * (= 'average'), B the blur of :78-79; H_delta the Huber function, delta = 0 the absolute value
+ * (huber_eps of ..._unger_prost.m:148-161).  These calls replace :82-172 of those files: problem
+ * assembly and solve.  Same conventions as the calls above (float32, column-major, status
+ * codes); mmc_sf_last_error(NULL) is the last mmc_sf_create failure of the calling thread. */
+typedef struct mmc_sf_handle mmc_sf_handle;
+typedef struct mmc_sf_params {
+    uint32_t size;             /* sizeof(mmc_sf_params) */
+    uint32_t version;          /* MMC_ABI_VERSION */
+    int32_t ny, nx;            /* low-resolution frame size */
+    int32_t factor;            /* zoom factor */
+    int32_t num_frames;        /* low-resolution frames; the central one is ceil(num_frames/2), 1-based (:21) */
+    float alpha;               /* weight of TV: ||q_j|| <= alpha (:163) */
+    float huber_eps;           /* delta >= 0 */
+    int32_t sampling;          /* MMC_SAMPLING_AVERAGE (factor 4) or MMC_SAMPLING_STRIDE */
+    int32_t device;
+    void *stream;              /* hipStream_t to queue on; NULL: the library makes one */
+} mmc_sf_params;
+int mmc_sf_create(const mmc_sf_params *params, mmc_sf_handle **out);
+int mmc_sf_destroy(mmc_sf_handle *h);
+const char *mmc_sf_last_error(const mmc_sf_handle *h);
+/* f: ny x nx x num_frames (J0 of :14-20) */
+int mmc_sf_set_lowres(mmc_sf_handle *h, const float *f);
+/* k: kh x kw, odd sizes, no negative entry (the step sizes take absolute row and column sums of
+ * D*B*W_i as sums of products); NULL: no blur */
+int mmc_sf_set_blur(mmc_sf_handle *h, const float *k, int kh, int kw);
+/* v: Ny x Nx x num_frames x 2 (:31-60; component 1 along columns, 2 along rows, as warpingOperator
+ * takes it at :69); the central frame's slice is ignored and taken as zero (:35-37).
+ * occ: NULL or Ny x Nx x num_frames, non-zero drops that row of W_i. */
+int mmc_sf_set_flow(mmc_sf_handle *h, const float *v, const uint8_t *occ);
+/* Start point, Ny x Nx; NULL: zero (prost.variable(N) starts there, :97).  Duals start at zero. */
+int mmc_sf_set_state(mmc_sf_handle *h, const float *u);
+/* Masks and diagonal step sizes; needs low-res data and flow. */
+int mmc_sf_init(mmc_sf_handle *h);
+/* As mmc_solve: at most max_iters iterations (:86-92: 7500 'accurate', 2500 otherwise); tol > 0
+ * stops on the relative change of the iterates, checked every check_every iterations. */
+int mmc_sf_solve(mmc_sf_handle *h, int max_iters, float tol, int check_every,
+                 mmc_stats *stats, mmc_progress_cb cb, void *user);
+int mmc_sf_get_state(mmc_sf_handle *h, float *u);       /* I of :172 */
+/* Test hooks.  K u: out_p num_frames*n, out_q 2N ([d/dcol; d/drow]).  K' y: out_u N.
+ * Steps: tau N, sigma_p num_frames*n, sigma_q N. */
+int mmc_sf_debug_apply_K(mmc_sf_handle *h, const float *u, float *out_p, float *out_q);
+int mmc_sf_debug_apply_KT(mmc_sf_handle *h, const float *p, const float *q, float *out_u);
+int mmc_sf_debug_steps(mmc_sf_handle *h, float *tau, float *sigma_p, float *sigma_q);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,8 @@ library has not been built.
 """
 from ._capi import MMCError  # noqa: F401
 
-__all__ = ["MMCError", "FrameBlockSolver", "SequenceGroupSolver", "MultiframeMotionCoupling", "MultiframeMotionCouplingAlternating"]
+__all__ = ["MMCError", "FrameBlockSolver", "SequenceGroupSolver", "MultiframeMotionCoupling", "MultiframeMotionCouplingAlternating",
+           "SingleFrameSolver", "singleframeMotionSR"]
 
 
 def __getattr__(name):
@@ -23,4 +24,7 @@ def __getattr__(name):
     if name == "MultiframeMotionCouplingAlternating":
         from .alternating import MultiframeMotionCouplingAlternating
         return MultiframeMotionCouplingAlternating
+    if name in ("SingleFrameSolver", "singleframeMotionSR"):
+        from . import singleframe
+        return getattr(singleframe, name)
     raise AttributeError(name)

@@ -39,6 +39,13 @@ class mmc_params(C.Structure):
                 ("stream", C.c_void_p)]
 
 
+class mmc_sf_params(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("version", C.c_uint32),
+                ("ny", C.c_int32), ("nx", C.c_int32), ("factor", C.c_int32), ("num_frames", C.c_int32),
+                ("alpha", C.c_float), ("huber_eps", C.c_float),
+                ("sampling", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p)]
+
+
 class mmc_stats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
                 ("res_primal", C.c_double), ("res_dual", C.c_double), ("solve_seconds", C.c_double)]
@@ -113,6 +120,19 @@ SIGNATURES = {
     "mmc_debug_steps": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),
     "mmc_debug_steps_update": (C.c_int, [_H, _fp, _fp]),
     "mmc_debug_plane_skew": (C.c_size_t, [_H]),
+    "mmc_sf_create": (C.c_int, [C.POINTER(mmc_sf_params), C.POINTER(_H)]),
+    "mmc_sf_destroy": (C.c_int, [_H]),
+    "mmc_sf_last_error": (C.c_char_p, [_H]),
+    "mmc_sf_set_lowres": (C.c_int, [_H, _fp]),
+    "mmc_sf_set_blur": (C.c_int, [_H, _fp, C.c_int, C.c_int]),
+    "mmc_sf_set_flow": (C.c_int, [_H, _fp, _u8p]),
+    "mmc_sf_set_state": (C.c_int, [_H, _fp]),
+    "mmc_sf_init": (C.c_int, [_H]),
+    "mmc_sf_solve": (C.c_int, [_H, C.c_int, C.c_float, C.c_int, C.POINTER(mmc_stats), PROGRESS_CB, C.c_void_p]),
+    "mmc_sf_get_state": (C.c_int, [_H, _fp]),
+    "mmc_sf_debug_apply_K": (C.c_int, [_H, _fp, _fp, _fp]),
+    "mmc_sf_debug_apply_KT": (C.c_int, [_H, _fp, _fp, _fp]),
+    "mmc_sf_debug_steps": (C.c_int, [_H, _fp, _fp, _fp]),
 }
 
 _lib = None

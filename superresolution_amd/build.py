@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmmc_hip.so")
-SOURCES = ["mmc_kernels.hip", "mmc_capi.cpp", "mmc_group.cpp"]
+SOURCES = ["mmc_kernels.hip", "mmc_capi.cpp", "mmc_group.cpp", "mmc_sf_kernels.hip", "mmc_sf.cpp"]
 
 
 def _hipcc():

@@ -783,6 +783,14 @@ static int build_data_operator(mmc_handle *h) {
     return MMC_OK;
 }
 
+const Geom *mmc_internal_geom(const mmc_handle *h) { return h ? &h->g : nullptr; }
+const Arrays *mmc_internal_arrays(const mmc_handle *h) { return h ? &h->a : nullptr; }
+int mmc_internal_build_data_operator(mmc_handle *h) {
+    REQUIRE_HANDLE(h);
+    int rc = use_device(h); if (rc) return rc;
+    return build_data_operator(h);
+}
+
 static int read_sums(mmc_handle *h, int first, int count, double *out) {
     std::vector<double> host((size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS);
     HIPCHK(h, hipMemcpyAsync(host.data(), h->a.sums, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -137,6 +137,28 @@ hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s);
 // the sweeps and leaves their contents unchanged; times how a placement of the planes performs.
 hipError_t mmc_launch_stream_probe(const Geom &g, float *const planes[12], int nf, bool dual_like, hipStream_t s);
 
+// ---- classical single-frame solve (mmc_sf.cpp, mmc_sf_kernels.hip) ------------------------------
+// Geometry and the data operator D*B (composite kernel, its column sums) come from a one-frame
+// mmc_handle that the single-frame handle owns.
+struct SfArrays {
+    int nf;                      // low-resolution frames = data terms
+    float alpha, delta;          // TV weight (ball radius of q), Huber parameter of the data terms
+    float *u, *ub;               // primal iterate and 2u+ - u, N each
+    float *qx, *qy;              // dual of the gradient (d/dcol, d/drow), N each
+    float *vx, *vy;              // flow from the central frame to frame i, nf*N each; NaN = masked row
+    float *p, *f, *sigp;         // data-term duals, low-res data, dual steps, nf*n each
+    float *tau;                  // primal steps, N
+    float *wimg;                 // W_i ub for every frame, nf*N (scratch of the dual half-iteration)
+    unsigned long long *acc;     // sum_i W_i' A' p_i in 64-bit fixed point (scale 2^40), N; zero between iterations
+    const float *cker, *cA;      // composite kernel CH x CW and absolute column sums of D*B (of the geometry handle)
+    double *sums;                // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]
+};
+// dual half-iteration: W_i ub, p and q updates; primal half-iteration: scatter and u update.
+// MODE_RAW applies K to ub (results in p, qx, qy) resp. K' to (p, q) (result in ub); MODE_STEPS
+// writes the dual steps to sigp, qx, qy resp. the primal steps to tau.
+hipError_t mmc_sf_launch_dual(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s);
+hipError_t mmc_sf_launch_primal(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s);
+
 // Failure of an entry point that has no handle and must not allocate: `literal` (a string literal)
 // becomes what mmc_last_error(NULL) returns on this thread; returns `code`.
 int mmc_static_fail(int code, const char *literal);
@@ -144,4 +166,8 @@ int mmc_static_fail(int code, const char *literal);
 // Used by the group driver (mmc_group.cpp), which owns one handle per frame block.
 struct mmc_handle;
 hipStream_t mmc_internal_stream(const mmc_handle *h);
+// Geometry and device arrays of a handle; the data operator (composite kernel, cA, sigp) is built on demand.
+const Geom *mmc_internal_geom(const mmc_handle *h);
+const Arrays *mmc_internal_arrays(const mmc_handle *h);
+int mmc_internal_build_data_operator(mmc_handle *h);
 int mmc_internal_set_flow_planes(mmc_handle *h, const float *vcol, const float *vrow, const uint8_t *occ);

@@ -45,3 +45,19 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64).ravel()
     b = np.asarray(b, dtype=np.float64).ravel()
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def make_sf_case(seed, ny, nx, nf, factor=4, flow="smooth", flow_scale=1.5, with_occ=False):
+    """Single-frame problem: low-res frames, flows from the central frame to every frame
+    (Ny,Nx,nf,2; the central slice is filled with garbage on purpose, it must be ignored) and
+    optional occlusion maps."""
+    rng = np.random.default_rng(seed)
+    Ny, Nx = factor * ny, factor * nx
+    f = np.clip(0.5 + 0.25 * np.stack([smooth_field(rng, (ny, nx), 1.0, 3) for _ in range(nf)], axis=2)
+                + 0.05 * rng.normal(size=(ny, nx, nf)), 0.0, 1.0)
+    v = np.zeros((Ny, Nx, nf, 2))
+    for i in range(nf):
+        for comp in range(2):
+            v[:, :, i, comp] = smooth_field(rng, (Ny, Nx), flow_scale) if flow == "smooth" else rng.normal(0.0, flow_scale, (Ny, Nx))
+    occ = (rng.random((Ny, Nx, nf)) < 0.1).astype(np.uint8) if with_occ else None
+    return f, v.astype(np.float32).astype(np.float64), occ

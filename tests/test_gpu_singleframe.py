@@ -1,0 +1,131 @@
+"""GPU parity of the classical single-frame solve (mmc_sf_*) against oracle/sf_oracle.py:
+operators, adjoint, step sizes, iterates at equal iteration counts, masks, Huber term,
+the mirror function, reproducibility.  Bars as for the multiframe solve: relative L2 <= 1e-4.
+Parity is unpinned against real prost output (the oracle restates the reference's text)."""
+import numpy as np
+import pytest
+
+import mmc_oracle as orc
+import sf_oracle as sfo
+from helpers import make_sf_case, rel_l2
+
+pytestmark = pytest.mark.gpu
+K7 = orc.fspecial_gaussian(7, 0.25 * np.sqrt(15.0))
+
+
+def _solver(f, v, occ=None, alpha=0.1, delta=0.0, k=K7, sampling="average", factor=4):
+    from superresolution_amd.singleframe import SingleFrameSolver
+    ny, nx, nf = f.shape
+    s = SingleFrameSolver(ny, nx, factor, nf, alpha=alpha, huber_eps=delta, sampling=sampling)
+    s.set_lowres(f); s.set_blur(k); s.set_flow(v, occ); s.set_state(None); s.init()
+    return s
+
+
+@pytest.mark.parametrize("flow,with_occ", [("smooth", False), ("random", True)])
+def test_operators_adjoint_and_steps(flow, with_occ):
+    f, v, occ = make_sf_case(11, 9, 11, 5, flow=flow, flow_scale=2.0, with_occ=with_occ)
+    P = sfo.build_problem(f, v, alpha=0.1, k=K7, occ=occ)
+    rng = np.random.default_rng(0)
+    with _solver(f, v, occ) as s:
+        u = rng.normal(size=(36, 44))
+        p, q = s.apply_K(u)
+        ref = P.K @ u.ravel(order="F")
+        m = P.n * P.nf
+        assert rel_l2(p, ref[:m]) < 1e-5 and rel_l2(q, ref[m:]) < 1e-5
+        y = rng.normal(size=P.K.shape[0])
+        kt = s.apply_KT(y[:m], y[m:])
+        assert rel_l2(kt, P.KT @ y) < 1e-5
+        # <K u, y> = <u, K' y> with the device operators alone
+        lhs = float(np.dot(np.concatenate([p, q]).astype(np.float64), y.astype(np.float32).astype(np.float64)))
+        rhs = float(np.dot(u.ravel(order="F").astype(np.float32).astype(np.float64), kt.astype(np.float64)))
+        assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0)
+        tau, sp_, sq = s.steps()
+        assert rel_l2(tau, P.T) < 1e-5
+        assert rel_l2(sp_, P.S[:m]) < 1e-5
+        assert rel_l2(sq, P.S[m:m + P.N]) < 1e-6
+
+
+@pytest.mark.parametrize("nf,delta,sampling,k", [(5, 0.0, "average", K7), (13, 0.01, "average", K7),
+                                                 (3, 0.0, "stride", K7), (4, 0.01, "average", None)])
+def test_solve_parity(nf, delta, sampling, k):
+    f, v, occ = make_sf_case(20 + nf, 8, 10, nf, flow_scale=1.5, with_occ=(nf == 5))
+    P = sfo.build_problem(f, v, alpha=0.1, huber_eps=delta, k=k, sampling=sampling, occ=occ)
+    x, _, chg = sfo.pdhg(P, 80)
+    with _solver(f, v, occ, delta=delta, k=k, sampling=sampling) as s:
+        st = s.solve(80, 0.0, 0)
+        u = s.get_state()
+    assert st["iterations"] == 80
+    assert rel_l2(u, sfo.image(P, x)) < 1e-4
+    assert abs(st["res_primal"] - chg[0] / chg[1]) < 1e-3 * chg[0] / chg[1] + 1e-7
+    assert abs(st["res_dual"] - chg[2] / chg[3]) < 1e-3 * chg[2] / chg[3] + 1e-7
+
+
+def test_other_zoom_factor_and_ragged_frame():
+    f, v, _ = make_sf_case(31, 7, 9, 3, factor=2)
+    k = orc.fspecial_gaussian(5, 0.7)
+    P = sfo.build_problem(f, v, factor=2, alpha=0.05, k=k, sampling="stride")
+    x, _, _ = sfo.pdhg(P, 60)
+    with _solver(f, v, alpha=0.05, k=k, sampling="stride", factor=2) as s:
+        s.solve(60)
+        assert rel_l2(s.get_state(), sfo.image(P, x)) < 1e-4
+
+
+def test_start_point_tolerance_stop_and_reproducibility():
+    f, v, _ = make_sf_case(32, 8, 8, 5)
+    P = sfo.build_problem(f, v, alpha=0.1, k=K7)
+    u0 = np.asfortranarray(orc.imresize(f[:, :, 2], 4))
+    x, _, _ = sfo.pdhg(P, 50, x=u0.ravel(order="F"))
+    outs = []
+    for _ in range(2):
+        with _solver(f, v) as s:
+            s.set_state(u0)
+            s.solve(50)
+            outs.append(s.get_state())
+    assert np.array_equal(outs[0], outs[1])
+    assert rel_l2(outs[0], sfo.image(P, x)) < 1e-4
+    seen = []
+    with _solver(f, v) as s:
+        st = s.solve(5000, 1e-3, 50, lambda it, d: seen.append(it) or False)
+        assert st["converged"] and st["iterations"] < 5000 and st["iterations"] % 50 == 0
+        assert seen and seen[-1] == st["iterations"]
+        e0 = sfo.primal_energy(P, np.zeros(P.N))
+        assert sfo.primal_energy(P, s.get_state().ravel(order="F").astype(np.float64)) < e0
+
+
+def test_mirror_function_colour_and_grey():
+    from superresolution_amd.singleframe import singleframeMotionSR
+    from superresolution_amd.mmc import rgb2ycbcr
+    rng = np.random.default_rng(5)
+    f, v, _ = make_sf_case(33, 8, 8, 5)
+    rgb = np.clip(np.stack([f, 0.9 * f + 0.05, 0.8 * f + 0.1], axis=2) + 0.01 * rng.normal(size=(8, 8, 3, 5)), 0, 1)
+    img, timings = singleframeMotionSR(rgb, 4, 0.1, v, comp_mode="fast", verbose=False)
+    assert img.shape == (32, 32, 3) and timings.shape == (2,) and timings[1] > 0
+    J0 = np.stack([rgb2ycbcr(rgb[:, :, :, i])[:, :, 0] for i in range(5)], axis=2)
+    P = sfo.build_problem(J0, v, alpha=0.1, k=K7)
+    # the luma of the result is the oracle's iterate after the 'fast' cap of 2500 iterations (:86-90)
+    x, _, _ = sfo.pdhg(P, 2500)
+    assert rel_l2(rgb2ycbcr(img)[:, :, 0], sfo.image(P, x)) < 2e-3       # through two colour conversions and a clip
+    grey, _ = singleframeMotionSR(J0, 4, 0.1, v, huber_eps=0.01, comp_mode="fast", verbose=False)
+    Ph = sfo.build_problem(J0, v, alpha=0.1, huber_eps=0.01, k=K7)
+    xh, _, _ = sfo.pdhg(Ph, 2500)
+    assert rel_l2(grey, sfo.image(Ph, xh)) < 1e-4
+
+
+def test_argument_errors():
+    from superresolution_amd import MMCError
+    from superresolution_amd.singleframe import SingleFrameSolver
+    with pytest.raises(MMCError):
+        SingleFrameSolver(8, 8, 4, 0)
+    with pytest.raises(MMCError):
+        SingleFrameSolver(8, 8, 4, 3, huber_eps=-1.0)
+    with pytest.raises(MMCError):
+        SingleFrameSolver(8, 8, 3, 3, sampling="average")         # a block mean only at factor 4
+    with SingleFrameSolver(8, 8, 4, 3) as s:
+        with pytest.raises(MMCError):
+            s.init()                                              # no data yet
+        with pytest.raises(MMCError):
+            s.set_blur(np.array([[0.5, -0.1, 0.6]]).T @ np.array([[0.2, 0.6, 0.2]]))
+        with pytest.raises(MMCError):
+            s.set_blur(np.ones((2, 2)))
+        with pytest.raises(ValueError):
+            s.set_flow(np.zeros((32, 32, 2, 2)))

@@ -10,5 +10,5 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $root/superresolution_amd/lib/variants
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -Wno-unused-function "$@" \
   -o $root/superresolution_amd/lib/variants/libmmc_$name.so \
-  $root/superresolution_amd/csrc/mmc_kernels.hip $root/superresolution_amd/csrc/mmc_capi.cpp $root/superresolution_amd/csrc/mmc_group.cpp 2>&1 | grep -E "error" || true
+  $root/superresolution_amd/csrc/mmc_kernels.hip $root/superresolution_amd/csrc/mmc_capi.cpp $root/superresolution_amd/csrc/mmc_group.cpp $root/superresolution_amd/csrc/mmc_sf_kernels.hip $root/superresolution_amd/csrc/mmc_sf.cpp 2>&1 | grep -E "error" || true
 ls -la $root/superresolution_amd/lib/variants/libmmc_$name.so
