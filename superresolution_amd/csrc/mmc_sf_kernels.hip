@@ -105,22 +105,44 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_q(Geom g, SfArrays a, c
     if (REDUCE) block_accumulate<2>(part, a.sums, 2);
 }
 
-// acc += W_i' z_i, z_i = A' p_i (MODE_UPDATE / MODE_RAW) or the column sums of A (MODE_STEPS)
+// acc += W_i' z_i, z_i = A' p_i (MODE_UPDATE / MODE_RAW) or the column sums of A (MODE_STEPS).
+// The lanes of a wave are consecutive rows of one column; where the flow is smooth, the lower tap
+// row of lane k is the upper tap row of lane k+1.  Lane k then adds its neighbour's upper
+// contributions to its own lower ones before the atomics (integer sums: the result does not depend on
+// who adds), which halves the number of atomics.
 template <int MODE>
 __global__ __launch_bounds__(MMC_THREADS) void k_sf_scatter(Geom g, SfArrays a) {
     const size_t idx = (size_t)blockIdx.x * MMC_THREADS + threadIdx.x;
-    if (idx >= (size_t)g.N * a.nf) return;
-    const int i = (int)(idx / g.N), j = (int)(idx - (size_t)i * g.N);
-    const int c = fdiv(j, g.dv_Ny), r = j - c * g.Ny;
-    const Taps tp = make_taps(g, r, c, a.vx[idx], a.vy[idx]);
-    if (!tp.valid) return;
-    const float z = MODE == MODE_STEPS ? a.cA[j] : gather_ATp(g, a.cker, a.p + (size_t)i * g.n, r, c);
-    if (z == 0.f) return;
-    const double s40 = fx_scaled(z);
-    if (tp.w00 != 0.f) fx_add(a.acc + tp.i00, tp.w00, s40);
-    if (tp.w10 != 0.f) fx_add(a.acc + tp.i10, tp.w10, s40);
-    if (tp.w01 != 0.f) fx_add(a.acc + tp.i01, tp.w01, s40);
-    if (tp.w11 != 0.f) fx_add(a.acc + tp.i11, tp.w11, s40);
+    const bool inside = idx < (size_t)g.N * a.nf;
+    int i00 = -1, i10 = -1, i01 = -1, i11 = -1;
+    fx64 f00 = 0, f10 = 0, f01 = 0, f11 = 0;
+    if (inside) {
+        const int i = (int)(idx / g.N), j = (int)(idx - (size_t)i * g.N);
+        const int c = fdiv(j, g.dv_Ny), r = j - c * g.Ny;
+        const Taps tp = make_taps(g, r, c, a.vx[idx], a.vy[idx]);
+        if (tp.valid) {
+            const float z = MODE == MODE_STEPS ? a.cA[j] : gather_ATp(g, a.cker, a.p + (size_t)i * g.n, r, c);
+            if (z != 0.f) {
+                const double s40 = fx_scaled(z);
+                i00 = tp.i00; i10 = tp.i10; i01 = tp.i01; i11 = tp.i11;
+                f00 = to_fx((double)tp.w00, s40); f10 = to_fx((double)tp.w10, s40);
+                f01 = to_fx((double)tp.w01, s40); f11 = to_fx((double)tp.w11, s40);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const int n00 = __shfl_down(i00, 1, 64), n01 = __shfl_down(i01, 1, 64);
+    const fx64 nf00 = __shfl_down(f00, 1, 64), nf01 = __shfl_down(f01, 1, 64);
+    const int p10 = __shfl_up(i10, 1, 64), p11 = __shfl_up(i11, 1, 64);
+    if (lane < 63 && i10 >= 0 && n00 == i10) f10 += nf00;
+    if (lane < 63 && i11 >= 0 && n01 == i11) f11 += nf01;
+    const bool given0 = lane > 0 && i00 >= 0 && p10 == i00;      // the previous lane has taken these
+    const bool given1 = lane > 0 && i01 >= 0 && p11 == i01;
+    if (i00 < 0) return;
+    if (!given0 && f00 != 0) atomicAdd(a.acc + i00, f00);
+    if (f10 != 0) atomicAdd(a.acc + i10, f10);
+    if (!given1 && f01 != 0) atomicAdd(a.acc + i01, f01);
+    if (f11 != 0) atomicAdd(a.acc + i11, f11);
 }
 
 // u+ = u - T (acc + G' q), ub = 2u+ - u; the accumulator is left at zero for the next iteration

@@ -129,3 +129,34 @@ def test_argument_errors():
             s.set_blur(np.ones((2, 2)))
         with pytest.raises(ValueError):
             s.set_flow(np.zeros((32, 32, 2, 2)))
+
+
+def test_city_size_13_frames_against_the_oracle():
+    """The size the reference runs its classical methods on (test_Mitzel_prost.m:6-14: 'city', 13
+    frames, factor 4 -> 576x704 high-resolution), parameters of testfile_full_set_SR_prost.m:52-54
+    (alpha 0.1, huber_eps 0.01); synthetic scene, analytic flows from the central frame plus a smooth
+    perturbation.  30 iterations at equal counts, then properties of a longer run."""
+    from superresolution_amd import synthetic
+    from helpers import smooth_field
+    ny, nx, nf = 144, 176, 13
+    Ny, Nx = 4 * ny, 4 * nx
+    blk = synthetic.make_block(ny, nx, nf, 0, nf, device="cpu")
+    f = np.asarray(blk["f"], dtype=np.float64)
+    rng = np.random.default_rng(7)
+    cs = sfo.central_slice(nf)
+    v = np.zeros((Ny, Nx, nf, 2))
+    for i in range(nf):
+        v[:, :, i, 0] = 0.7 * (i - cs) + smooth_field(rng, (Ny, Nx), 0.3)
+        v[:, :, i, 1] = -0.4 * (i - cs) + smooth_field(rng, (Ny, Nx), 0.3)
+    v = v.astype(np.float32).astype(np.float64)
+    P = sfo.build_problem(f, v, alpha=0.1, huber_eps=0.01, k=K7)
+    x, _, _ = sfo.pdhg(P, 30)
+    with _solver(f, v, delta=0.01) as s:
+        s.solve(30)
+        u30 = s.get_state()
+        assert rel_l2(u30, sfo.image(P, x)) < 1e-4
+        assert float(np.abs(u30 - sfo.image(P, x)).max()) < 1e-4
+        e30 = sfo.primal_energy(P, u30.ravel(order="F").astype(np.float64))
+        st = s.solve(300, 0.0, 100)
+        e330 = sfo.primal_energy(P, s.get_state().ravel(order="F").astype(np.float64))
+        assert e330 < e30 and st["res_primal"] < 5e-3
