@@ -141,9 +141,10 @@ def test_group_create_without_gpu_reports_no_device():
 
 
 def test_mex_gateway_type_checks_against_the_header():
-    """mex/mmc_hip_mex.cpp cannot be built without MATLAB; compiled against a declaration-only mex.h
-    (tests/mex_stub) every mmc_* call in it is at least checked against include/mmc_hip.h."""
+    """The gateways under mex/ cannot be built without MATLAB; compiled against a declaration-only mex.h
+    (tests/mex_stub) every mmc_* call in them is at least checked against include/mmc_hip.h."""
     import subprocess
-    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
-                    "-I", os.path.join(ROOT, "tests", "mex_stub"), "-I", os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "mex", "mmc_hip_mex.cpp")], check=True)
+    for src in ("mmc_hip_mex.cpp", "mmc_sf_mex.cpp"):
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "tests", "mex_stub"), "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "mex", src)], check=True)
