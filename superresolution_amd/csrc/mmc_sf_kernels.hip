@@ -73,6 +73,57 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_p(Geom g, SfArrays a) {
     if (REDUCE) block_accumulate<2>(part, a.sums, 2);
 }
 
+// The two kernels above in one, per tile of SF_TL x SF_TL low-resolution pixels of one frame: the
+// window of W_i ub that the tile's rows of A touch (tile * zoom + kernel halo, replicate border applied
+// while staging) is computed straight into LDS, the composite kernel is applied from there.  Saves the
+// scratch plane's write and read; the flow is read once per window pixel (halo: 1.2x at zoom 4).
+enum { SF_TL = 16, SF_WIN_MAX = 12032 };        // window floats that fit next to the kernel table in 48 KB of LDS
+template <int MODE, bool REDUCE>
+__global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_tile(Geom g, SfArrays a, const float *__restrict__ img, int tiles_R) {
+    extern __shared__ __align__(16) float lds[];
+    const int SR = SF_TL * g.f + g.CH - g.f, SC = SF_TL * g.f + g.CW - g.f;
+    float *win = lds, *ck = lds + SR * SC;
+    const int i = blockIdx.y;
+    const int tC = blockIdx.x / tiles_R, tR = blockIdx.x - tC * tiles_R;
+    const int R0 = SF_TL * tR, C0 = SF_TL * tC;
+    const int wr0 = g.f * R0 + g.oy, wc0 = g.f * C0 + g.ox;
+    const float *vx = a.vx + (size_t)i * g.N, *vy = a.vy + (size_t)i * g.N;
+    for (int k = threadIdx.x; k < g.CH * g.CW; k += MMC_THREADS) ck[k] = a.cker[k];
+    for (int k = threadIdx.x; k < SR * SC; k += MMC_THREADS) {
+        const int kc = k / SR, kr = k - kc * SR;
+        const int r = min(max(wr0 + kr, 0), g.Ny - 1), c = min(max(wc0 + kc, 0), g.Nx - 1);
+        const int j = r + g.Ny * c;
+        const Taps tp = make_taps(g, r, c, vx[j], vy[j]);
+        float out = 0.f;
+        if (tp.valid) out = MODE == MODE_STEPS ? 1.f : sample(tp, img);
+        win[k] = out;
+    }
+    __syncthreads();
+    float part[2] = {0.f, 0.f};
+    for (int l = threadIdx.x; l < SF_TL * SF_TL; l += MMC_THREADS) {
+        const int Cl = l / SF_TL, Rl = l - Cl * SF_TL;
+        const int R = R0 + Rl, C = C0 + Cl;
+        if (R >= g.ny || C >= g.nx) continue;
+        float acc = 0.f;
+        for (int nn = 0; nn < g.CW; ++nn) {
+            const float *col = win + g.f * Rl + SR * (g.f * Cl + nn);
+            for (int mm = 0; mm < g.CH; ++mm) acc += ck[mm + g.CH * nn] * col[mm];
+        }
+        const size_t idx = (size_t)i * g.n + R + (size_t)g.ny * C;
+        if (MODE == MODE_RAW) {
+            a.p[idx] = acc;
+        } else if (MODE == MODE_STEPS) {
+            a.sigp[idx] = acc > 0.f ? 1.f / acc : 1.f;
+        } else {
+            const float sg = a.sigp[idx], po = a.p[idx];
+            const float pn = fminf(fmaxf((po + sg * (acc - a.f[idx])) / (1.f + sg * a.delta), -1.f), 1.f);
+            a.p[idx] = pn;
+            if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; }
+        }
+    }
+    if (REDUCE) block_accumulate<2>(part, a.sums, 2);
+}
+
 // q <- projection of q + s G ub onto ||q_j|| <= alpha  (sum_norm2(2,false,'ind_leq0',1/alpha,...), :163)
 template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_q(Geom g, SfArrays a, const float *__restrict__ img) {
@@ -180,26 +231,26 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_primal(Geom g, SfArrays a) {
 
 static dim3 grid_for(size_t count) { return dim3((unsigned)((count + MMC_THREADS - 1) / MMC_THREADS)); }
 
-hipError_t mmc_sf_launch_dual(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s) {
+template <int MODE, bool REDUCE>
+static void launch_dual_mode(const Geom &g, const SfArrays &a, hipStream_t s) {
     const dim3 block(MMC_THREADS);
-    const size_t npix = (size_t)g.N * a.nf, nlr = (size_t)g.n * a.nf;
-    if (mode == MODE_STEPS) {
-        hipLaunchKernelGGL(k_sf_warp<MODE_STEPS>, grid_for(npix), block, 0, s, g, a, a.ub);
-        hipLaunchKernelGGL((k_sf_dual_p<MODE_STEPS, false>), grid_for(nlr), block, 0, s, g, a);
-        hipLaunchKernelGGL((k_sf_dual_q<MODE_STEPS, false>), grid_for((size_t)g.N), block, 0, s, g, a, a.ub);
-    } else if (mode == MODE_RAW) {
-        hipLaunchKernelGGL(k_sf_warp<MODE_RAW>, grid_for(npix), block, 0, s, g, a, a.ub);
-        hipLaunchKernelGGL((k_sf_dual_p<MODE_RAW, false>), grid_for(nlr), block, 0, s, g, a);
-        hipLaunchKernelGGL((k_sf_dual_q<MODE_RAW, false>), grid_for((size_t)g.N), block, 0, s, g, a, a.ub);
-    } else if (reduce) {
-        hipLaunchKernelGGL(k_sf_warp<MODE_UPDATE>, grid_for(npix), block, 0, s, g, a, a.ub);
-        hipLaunchKernelGGL((k_sf_dual_p<MODE_UPDATE, true>), grid_for(nlr), block, 0, s, g, a);
-        hipLaunchKernelGGL((k_sf_dual_q<MODE_UPDATE, true>), grid_for((size_t)g.N), block, 0, s, g, a, a.ub);
+    const int SR = SF_TL * g.f + g.CH - g.f, SC = SF_TL * g.f + g.CW - g.f;
+    if (SR * SC <= SF_WIN_MAX) {
+        const int tiles_R = (g.ny + SF_TL - 1) / SF_TL, tiles_C = (g.nx + SF_TL - 1) / SF_TL;
+        const size_t lds = (size_t)(SR * SC + g.CH * g.CW) * sizeof(float);
+        hipLaunchKernelGGL((k_sf_dual_tile<MODE, REDUCE>), dim3(tiles_R * tiles_C, a.nf), block, lds, s, g, a, a.ub, tiles_R);
     } else {
-        hipLaunchKernelGGL(k_sf_warp<MODE_UPDATE>, grid_for(npix), block, 0, s, g, a, a.ub);
-        hipLaunchKernelGGL((k_sf_dual_p<MODE_UPDATE, false>), grid_for(nlr), block, 0, s, g, a);
-        hipLaunchKernelGGL((k_sf_dual_q<MODE_UPDATE, false>), grid_for((size_t)g.N), block, 0, s, g, a, a.ub);
+        hipLaunchKernelGGL(k_sf_warp<MODE>, grid_for((size_t)g.N * a.nf), block, 0, s, g, a, a.ub);
+        hipLaunchKernelGGL((k_sf_dual_p<MODE, REDUCE>), grid_for((size_t)g.n * a.nf), block, 0, s, g, a);
     }
+    hipLaunchKernelGGL((k_sf_dual_q<MODE, REDUCE>), grid_for((size_t)g.N), block, 0, s, g, a, a.ub);
+}
+
+hipError_t mmc_sf_launch_dual(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s) {
+    if (mode == MODE_STEPS) launch_dual_mode<MODE_STEPS, false>(g, a, s);
+    else if (mode == MODE_RAW) launch_dual_mode<MODE_RAW, false>(g, a, s);
+    else if (reduce) launch_dual_mode<MODE_UPDATE, true>(g, a, s);
+    else launch_dual_mode<MODE_UPDATE, false>(g, a, s);
     return hipGetLastError();
 }
 
