@@ -149,7 +149,11 @@ struct SfArrays {
     float *p, *f, *sigp;         // data-term duals, low-res data, dual steps, nf*n each
     float *tau;                  // primal steps, N
     float *wimg;                 // W_i ub for every frame, nf*N (scratch of the dual half-iteration)
-    unsigned long long *acc;     // sum_i W_i' A' p_i in 64-bit fixed point (scale 2^40), N; zero between iterations
+    unsigned long long *acc;     // W_i' A' p_i of the irregular frames in 64-bit fixed point (scale 2^40), N; zero between iterations
+    int *bbox;                   // [nf][ntiles][4] = rmin,rmax,cmin,cmax of the source pixels with a tap in the tile (64 x 16 tiles)
+    int *irregular;              // [nf] 1: some tile's source rectangle of this frame is too large to walk (violent flow);
+                                 //      the frame is scattered with global atomics instead
+    int any_irregular;
     const float *cker, *cA;      // composite kernel CH x CW and absolute column sums of D*B (of the geometry handle)
     double *sums;                // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]
 };
@@ -158,6 +162,9 @@ struct SfArrays {
 // writes the dual steps to sigp, qx, qy resp. the primal steps to tau.
 hipError_t mmc_sf_launch_dual(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s);
 hipError_t mmc_sf_launch_primal(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s);
+// source rectangles of every (frame, tile) from the flows: a.bbox
+hipError_t mmc_sf_launch_bbox(const Geom &g, const SfArrays &a, hipStream_t s);
+enum { MMC_SF_BOX_MAX = 6144 };   // largest source rectangle (pixels) the tile kernel walks
 
 // Failure of an entry point that has no handle and must not allocate: `literal` (a string literal)
 // becomes what mmc_last_error(NULL) returns on this thread; returns `code`.

@@ -110,6 +110,7 @@ extern "C" int mmc_sf_create(const mmc_sf_params *p, mmc_sf_handle **out) {
         (rc = sf_alloc(h, &a.vx, nf * N)) || (rc = sf_alloc(h, &a.vy, nf * N)) || (rc = sf_alloc(h, &a.wimg, nf * N)) ||
         (rc = sf_alloc(h, &a.p, nf * n)) || (rc = sf_alloc(h, &a.f, nf * n)) || (rc = sf_alloc(h, &a.sigp, nf * n)) ||
         (rc = sf_alloc(h, &a.tau, N)) || (rc = sf_alloc(h, &a.acc, N)) ||
+        (rc = sf_alloc(h, &a.bbox, nf * (size_t)g.ntiles * 4)) || (rc = sf_alloc(h, &a.irregular, nf)) ||
         (rc = sf_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)))
         return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(sfail(h, MMC_ERR_HIP, "hipStreamSynchronize failed"));
@@ -196,6 +197,21 @@ extern "C" int mmc_sf_init(mmc_sf_handle *h) {
     const Arrays &ga = *mmc_internal_arrays(h->geo);
     h->a.cker = ga.cker;
     h->a.cA = ga.cA;
+    // source rectangles of the tile scatter; a frame with a rectangle too large to walk is scattered with global atomics
+    {
+        SFHIP(h, mmc_sf_launch_bbox(g, h->a, h->stream));
+        std::vector<int> bb((size_t)h->nf * g.ntiles * 4), irr((size_t)h->nf, 0);
+        SFHIP(h, hipMemcpyAsync(bb.data(), h->a.bbox, bb.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        SFHIP(h, hipStreamSynchronize(h->stream));
+        h->a.any_irregular = 0;
+        for (int i = 0; i < h->nf; ++i)
+            for (int t = 0; t < g.ntiles; ++t) {
+                const int *b = &bb[((size_t)i * g.ntiles + t) * 4];
+                if (b[1] >= b[0] && (long long)(b[1] - b[0] + 1) * (b[3] - b[2] + 1) > MMC_SF_BOX_MAX) { irr[(size_t)i] = 1; h->a.any_irregular = 1; }
+            }
+        SFHIP(h, hipMemcpyAsync(h->a.irregular, irr.data(), irr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        SFHIP(h, hipStreamSynchronize(h->stream));
+    }
     // step sizes: the operators applied to constant input (no entry of K is negative); the duals
     // hold the dual steps for a moment and are cleared again
     std::vector<float> keep_u((size_t)h->N), keep_ub((size_t)h->N);

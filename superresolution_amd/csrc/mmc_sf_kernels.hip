@@ -10,14 +10,20 @@
 //   primal  u+ = u - T (sum_i W_i' A' p_i + G' q),   ub = 2u+ - u
 //   dual    p_i <- clamp((p_i + S (A W_i ub - f_i)) / (1 + S delta), -1, 1)
 //           q   <- projection of q + S G ub onto the alpha-balls
-// Five simple kernels per iteration.  This is the comparison method of the reference, built for
-// parity and completeness; it is not tuned like the sweeps of mmc_kernels.hip:
-//   k_sf_warp     W_i ub for all frames into a scratch plane per frame (4-tap gather)
-//   k_sf_dual_p   A (W_i ub) per low-resolution pixel from that plane, p update
-//   k_sf_dual_q   gradient of ub, q update
-//   k_sf_scatter  W_i' (A' p_i): per source pixel the gather form of A' p_i, then four 64-bit
-//                 fixed-point global atomics (order-independent, so runs are bitwise reproducible)
-//   k_sf_primal   u update from the accumulator (cleared on the way) and G' q
+// Three kernels per iteration (this is the comparison method of the reference; it follows the design
+// of the sweeps in mmc_kernels.hip without their tuning):
+//   k_sf_dual_tile    per tile of 16 x 16 low-resolution pixels of a frame: the window of W_i ub that
+//                     the tile's rows of A touch goes straight into LDS, A from there, p update
+//                     (k_sf_warp + k_sf_dual_p through a scratch plane when the window does not fit)
+//   k_sf_dual_q       gradient of ub, q update
+//   k_sf_atp          A' p_i at every pixel of every frame, gather form, into the scratch plane
+//   k_sf_scatter_tile per 64 x 16 target tile and group of frames: walk the rectangle of sources with
+//                     a tap in the tile (k_sf_bbox at set-up), tap contributions added in LDS as 64-bit
+//                     fixed point, one global atomic per pixel and group into a.acc.  Integer sums are
+//                     order-independent, so runs are bitwise reproducible.
+//   k_sf_scatter      frames whose flow is too violent for rectangles (a.irregular) go through
+//                     per-tap 64-bit global atomics into a.acc instead
+//   k_sf_primal       G' q and the u update from a.acc (cleared on the way)
 // The same kernels applied to constant input give the diagonal step sizes (the operator has no
 // negative entry, which the host checks, so absolute row and column sums are K 1 and K' 1).
 #include <hip/hip_runtime.h>
@@ -27,12 +33,20 @@
 
 #include "mmc_device.h"
 
+// k / d and k % d for 0 <= k < 2^23 and a workgroup-uniform d through one float multiply (inv = 1/d)
+__device__ __forceinline__ void divmod_small(int k, int d, float inv, int &q, int &rem) {
+    q = (int)(((float)k + 0.5f) * inv);
+    rem = k - q * d;
+    if (rem < 0) { --q; rem += d; }
+    if (rem >= d) { ++q; rem -= d; }
+}
+
 // W_i img for every frame i (MODE_RAW / MODE_UPDATE), or the row mask of W_i (MODE_STEPS)
 template <int MODE>
 __global__ __launch_bounds__(MMC_THREADS) void k_sf_warp(Geom g, SfArrays a, const float *__restrict__ img) {
-    const size_t idx = (size_t)blockIdx.x * MMC_THREADS + threadIdx.x;
-    if (idx >= (size_t)g.N * a.nf) return;
-    const int i = (int)(idx / g.N), j = (int)(idx - (size_t)i * g.N);
+    const int i = blockIdx.y, j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    const size_t idx = (size_t)i * g.N + j;
     const int c = fdiv(j, g.dv_Ny), r = j - c * g.Ny;
     const Taps tp = make_taps(g, r, c, a.vx[idx], a.vy[idx]);
     float out = 0.f;
@@ -89,8 +103,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_tile(Geom g, SfArrays a
     const int wr0 = g.f * R0 + g.oy, wc0 = g.f * C0 + g.ox;
     const float *vx = a.vx + (size_t)i * g.N, *vy = a.vy + (size_t)i * g.N;
     for (int k = threadIdx.x; k < g.CH * g.CW; k += MMC_THREADS) ck[k] = a.cker[k];
+    const float inv_sr = 1.f / (float)SR;
     for (int k = threadIdx.x; k < SR * SC; k += MMC_THREADS) {
-        const int kc = k / SR, kr = k - kc * SR;
+        int kc, kr;
+        divmod_small(k, SR, inv_sr, kc, kr);
         const int r = min(max(wr0 + kr, 0), g.Ny - 1), c = min(max(wc0 + kc, 0), g.Nx - 1);
         const int j = r + g.Ny * c;
         const Taps tp = make_taps(g, r, c, vx[j], vy[j]);
@@ -156,6 +172,36 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_q(Geom g, SfArrays a, c
     if (REDUCE) block_accumulate<2>(part, a.sums, 2);
 }
 
+// z_i(r,c) = (A' p_i)(r,c), or the column sum of A there (MODE_STEPS).  Zoom 4 away from the frame
+// border: with x = r - oy the low-resolution rows that have a kernel row on r are R = (x >> 2) - jr with
+// kernel row (x & 3) + 4 jr, jr < Jr; a fixed Jr x Jc loop with masked terms, so that the loads of
+// several sources can be in flight together.  Border pixels take the general gather (gather_ATp), which
+// handles the virtual rows and columns that the replicate border folds onto the frame's edge.
+template <int MODE>
+__device__ __forceinline__ float sf_z(const Geom &g, const SfArrays &a, int i, int r, int c, int j) {
+    if (MODE == MODE_STEPS) return a.cA[j];
+    const float *p = a.p + (size_t)i * g.n;
+    if (g.f == 4 && r > 0 && r < g.Ny - 1 && c > 0 && c < g.Nx - 1) {
+        const int x = r - g.oy, y = c - g.ox;
+        const int R0 = x >> 2, C0 = y >> 2, m0 = x & 3, n0 = y & 3;
+        float acc = 0.f;
+        for (int jc = 0; jc < g.Jc; ++jc) {
+            const int C = C0 - jc, nn = n0 + 4 * jc;
+            const bool okc = C >= 0 && C < g.nx && nn < g.CW;
+            const float *ck = a.cker + g.CH * min(nn, g.CW - 1);
+            const float *pc = p + g.ny * min(max(C, 0), g.nx - 1);
+            for (int jr = 0; jr < g.Jr; ++jr) {
+                const int R = R0 - jr, mm = m0 + 4 * jr;
+                const bool ok = okc && R >= 0 && R < g.ny && mm < g.CH;
+                const float t = ck[min(mm, g.CH - 1)] * pc[min(max(R, 0), g.ny - 1)];
+                acc += ok ? t : 0.f;
+            }
+        }
+        return acc;
+    }
+    return gather_ATp(g, a.cker, p, r, c);
+}
+
 // acc += W_i' z_i, z_i = A' p_i (MODE_UPDATE / MODE_RAW) or the column sums of A (MODE_STEPS).
 // The lanes of a wave are consecutive rows of one column; where the flow is smooth, the lower tap
 // row of lane k is the upper tap row of lane k+1.  Lane k then adds its neighbour's upper
@@ -163,16 +209,18 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_q(Geom g, SfArrays a, c
 // who adds), which halves the number of atomics.
 template <int MODE>
 __global__ __launch_bounds__(MMC_THREADS) void k_sf_scatter(Geom g, SfArrays a) {
-    const size_t idx = (size_t)blockIdx.x * MMC_THREADS + threadIdx.x;
-    const bool inside = idx < (size_t)g.N * a.nf;
+    const int i = blockIdx.y, j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    const bool inside = j < g.N;
+    const size_t idx = (size_t)i * g.N + (inside ? j : 0);
     int i00 = -1, i10 = -1, i01 = -1, i11 = -1;
     fx64 f00 = 0, f10 = 0, f01 = 0, f11 = 0;
     if (inside) {
-        const int i = (int)(idx / g.N), j = (int)(idx - (size_t)i * g.N);
         const int c = fdiv(j, g.dv_Ny), r = j - c * g.Ny;
-        const Taps tp = make_taps(g, r, c, a.vx[idx], a.vy[idx]);
+        Taps tp;
+        tp.valid = false;
+        if (a.irregular[i]) tp = make_taps(g, r, c, a.vx[idx], a.vy[idx]);     // the other frames are scattered per tile
         if (tp.valid) {
-            const float z = MODE == MODE_STEPS ? a.cA[j] : gather_ATp(g, a.cker, a.p + (size_t)i * g.n, r, c);
+            const float z = sf_z<MODE>(g, a, i, r, c, j);
             if (z != 0.f) {
                 const double s40 = fx_scaled(z);
                 i00 = tp.i00; i10 = tp.i10; i01 = tp.i01; i11 = tp.i11;
@@ -194,6 +242,151 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_scatter(Geom g, SfArrays a) 
     if (f10 != 0) atomicAdd(a.acc + i10, f10);
     if (!given1 && f01 != 0) atomicAdd(a.acc + i01, f01);
     if (f11 != 0) atomicAdd(a.acc + i11, f11);
+}
+
+// Source rectangles: for every frame and every 64 x 16 tile the bounding box of the source pixels
+// with at least one tap inside the tile.
+__global__ __launch_bounds__(MMC_THREADS) void k_sf_bbox_clear(int *bbox, int count) {
+    const int k = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (k < count) bbox[k] = (k & 1) ? -1 : INT_MAX;            // rmin, rmax, cmin, cmax
+}
+
+__global__ __launch_bounds__(MMC_THREADS) void k_sf_bbox(Geom g, SfArrays a) {
+    const int i = blockIdx.y, j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    const size_t idx = (size_t)i * g.N + j;
+    const int c = fdiv(j, g.dv_Ny), r = j - c * g.Ny;
+    const Taps tp = make_taps(g, r, c, a.vx[idx], a.vy[idx]);
+    if (!tp.valid) return;
+    const int tr0 = tp.r0 / TILE_R, tr1 = tp.r1 / TILE_R, tc0 = tp.c0 / TILE_C, tc1 = tp.c1 / TILE_C;
+    int *base = a.bbox + (size_t)i * g.ntiles * 4;
+    for (int kc = 0; kc < 2; ++kc) {
+        if (kc == 1 && tc1 == tc0) break;
+        for (int kr = 0; kr < 2; ++kr) {
+            if (kr == 1 && tr1 == tr0) break;
+            int *bb = base + ((kr ? tr1 : tr0) + g.tiles_r * (kc ? tc1 : tc0)) * 4;
+            atomicMin(bb + 0, r); atomicMax(bb + 1, r); atomicMin(bb + 2, c); atomicMax(bb + 3, c);
+        }
+    }
+}
+
+// z_i at every pixel of every regular frame into the scratch plane: fully parallel, so that the
+// tile scatter below reads one float per source.
+template <int MODE>
+__global__ __launch_bounds__(MMC_THREADS) void k_sf_atp(Geom g, SfArrays a) {
+    const int i = blockIdx.y, j = blockIdx.x * MMC_THREADS + threadIdx.x;
+    if (j >= g.N) return;
+    const size_t idx = (size_t)i * g.N + j;
+    if (a.irregular[i]) return;
+    const int c = fdiv(j, g.dv_Ny), r = j - c * g.Ny;
+    a.wimg[idx] = sf_z<MODE>(g, a, i, r, c, j);
+}
+
+// The same at zoom 4 with wave-uniform kernel phases: a workgroup takes a 64 x 16 tile of frame i in 16
+// passes of 64 pixels that share (row mod 4, column mod 4), one pass per (wave, step).  The kernel entry of a
+// tap then depends on the pass only (scalar loads, uniform bounds), the low-resolution rows of the 64 lanes
+// are consecutive, and what is left per pixel is Jr x Jc loads of p and as many multiply-adds.
+__global__ __launch_bounds__(MMC_THREADS) void k_sf_atp4(Geom g, SfArrays a) {
+    const int i = blockIdx.y, tile = blockIdx.x;
+    if (a.irregular[i]) return;
+    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
+    const int r0 = tr * TILE_R, c0 = tc * TILE_C;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const float *p = a.p + (size_t)i * g.n;
+    float *z = a.wimg + (size_t)i * g.N;
+    for (int step = 0; step < 4; ++step) {
+        const int phase = wave * 4 + step, pr = phase & 3, pc = phase >> 2;
+        const int r = r0 + 4 * (lane & 15) + pr, c = c0 + 4 * (lane >> 4) + pc;
+        if (r >= g.Ny || c >= g.Nx) continue;
+        const int j = r + g.Ny * c;
+        if (r == 0 || r == g.Ny - 1 || c == 0 || c == g.Nx - 1) { z[j] = gather_ATp(g, a.cker, p, r, c); continue; }
+        // x = r - oy, y = c - ox: phases and the first low-resolution row / column of lane 0 are uniform
+        const int xb = r0 + pr - g.oy, yb = c0 + pc - g.ox;
+        const int m0 = xb & 3, n0 = yb & 3;
+        const int R0 = (xb >> 2) + (lane & 15), C0 = (yb >> 2) + (lane >> 4);
+        float acc = 0.f;
+        for (int jc = 0; jc < g.Jc; ++jc) {
+            const int nn = n0 + 4 * jc;
+            if (nn >= g.CW) break;
+            const int C = C0 - jc;
+            const bool okc = C >= 0 && C < g.nx;
+            const float *pcol = p + g.ny * min(max(C, 0), g.nx - 1);
+            for (int jr = 0; jr < g.Jr; ++jr) {
+                const int mm = m0 + 4 * jr;
+                if (mm >= g.CH) break;
+                const float wgt = a.cker[mm + g.CH * nn];
+                const int R = R0 - jr;
+                const float t = wgt * pcol[min(max(R, 0), g.ny - 1)];
+                acc += (okc && R >= 0 && R < g.ny) ? t : 0.f;
+            }
+        }
+        z[j] = acc;
+    }
+}
+
+// W' of the primal half-iteration per target tile and frame group: workgroup (tile, grp) walks, for
+// the regular frames i = grp, grp + ngroups, ..., the source rectangle of its tile, takes A' p_i
+// (k_sf_atp) at every source with a tap inside the tile and adds the tap contributions in LDS (64-bit
+// fixed point, integer atomics); the tile's sums then go to a.acc with one global atomic per pixel.
+// Splitting the frames over groups keeps small frames from leaving most CUs idle.
+__global__ __launch_bounds__(MMC_THREADS) void k_sf_scatter_tile(Geom g, SfArrays a, int ngroups) {
+    __shared__ fx64 acc[TILE_R * TILE_C];
+    const int tile = blockIdx.x, grp = blockIdx.y;
+    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
+    const int r0 = tr * TILE_R, c0 = tc * TILE_C;
+    for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) acc[k] = 0;
+    __syncthreads();
+    bool any = false;
+    for (int i = grp; i < a.nf; i += ngroups) {
+        if (a.irregular[i]) continue;
+        const int *bb = a.bbox + ((size_t)i * g.ntiles + tile) * 4;
+        const int rmin = bb[0], rmax = bb[1], cmin = bb[2], cmax = bb[3];
+        if (rmax < rmin) continue;
+        any = true;
+        const int bh = rmax - rmin + 1, cnt = bh * (cmax - cmin + 1);
+        const float inv_bh = 1.f / (float)bh;
+        const float *vx = a.vx + (size_t)i * g.N, *vy = a.vy + (size_t)i * g.N, *zi = a.wimg + (size_t)i * g.N;
+        // four sources per thread and pass: their flow loads are issued together
+        for (int kb = threadIdx.x; kb < cnt; kb += 4 * MMC_THREADS) {
+            int sr[4], sc[4];
+            float fx[4], fy[4], zz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u * MMC_THREADS;
+                const bool ok = k < cnt;
+                int kc = 0, kr = 0;
+                if (ok) divmod_small(k, bh, inv_bh, kc, kr);
+                sr[u] = ok ? rmin + kr : -1;
+                sc[u] = cmin + kc;
+                const int j = ok ? sr[u] + g.Ny * sc[u] : 0;
+                fx[u] = vx[j]; fy[u] = vy[j]; zz[u] = zi[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (sr[u] < 0) continue;
+                const Taps tp = make_taps(g, sr[u], sc[u], fx[u], fy[u]);
+                if (!tp.valid) continue;
+                const bool ra = tp.r0 >= r0 && tp.r0 < r0 + TILE_R, rb = tp.r1 >= r0 && tp.r1 < r0 + TILE_R;
+                const bool ca = tp.c0 >= c0 && tp.c0 < c0 + TILE_C, cb = tp.c1 >= c0 && tp.c1 < c0 + TILE_C;
+                if (!((ra || rb) && (ca || cb))) continue;
+                const float z = zz[u];
+                if (z == 0.f) continue;
+                const double s40 = fx_scaled(z);
+                if (ra && ca && tp.w00 != 0.f) fx_add(acc + (tp.r0 - r0) + TILE_R * (tp.c0 - c0), tp.w00, s40);
+                if (rb && ca && tp.w10 != 0.f) fx_add(acc + (tp.r1 - r0) + TILE_R * (tp.c0 - c0), tp.w10, s40);
+                if (ra && cb && tp.w01 != 0.f) fx_add(acc + (tp.r0 - r0) + TILE_R * (tp.c1 - c0), tp.w01, s40);
+                if (rb && cb && tp.w11 != 0.f) fx_add(acc + (tp.r1 - r0) + TILE_R * (tp.c1 - c0), tp.w11, s40);
+            }
+        }
+    }
+    if (!any) return;            // uniform over the workgroup
+    __syncthreads();
+    for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) {
+        const int lc = k / TILE_R, lr = k - lc * TILE_R;
+        const int r = r0 + lr, c = c0 + lc;
+        if (r >= g.Ny || c >= g.Nx || acc[k] == 0) continue;
+        atomicAdd(a.acc + r + (size_t)g.Ny * c, acc[k]);
+    }
 }
 
 // u+ = u - T (acc + G' q), ub = 2u+ - u; the accumulator is left at zero for the next iteration
@@ -230,6 +423,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_primal(Geom g, SfArrays a) {
 // --------------------------------------------------------------------------
 
 static dim3 grid_for(size_t count) { return dim3((unsigned)((count + MMC_THREADS - 1) / MMC_THREADS)); }
+static dim3 grid_frames(const Geom &g, const SfArrays &a) { return dim3((unsigned)((g.N + MMC_THREADS - 1) / MMC_THREADS), (unsigned)a.nf); }
 
 template <int MODE, bool REDUCE>
 static void launch_dual_mode(const Geom &g, const SfArrays &a, hipStream_t s) {
@@ -240,7 +434,7 @@ static void launch_dual_mode(const Geom &g, const SfArrays &a, hipStream_t s) {
         const size_t lds = (size_t)(SR * SC + g.CH * g.CW) * sizeof(float);
         hipLaunchKernelGGL((k_sf_dual_tile<MODE, REDUCE>), dim3(tiles_R * tiles_C, a.nf), block, lds, s, g, a, a.ub, tiles_R);
     } else {
-        hipLaunchKernelGGL(k_sf_warp<MODE>, grid_for((size_t)g.N * a.nf), block, 0, s, g, a, a.ub);
+        hipLaunchKernelGGL(k_sf_warp<MODE>, grid_frames(g, a), block, 0, s, g, a, a.ub);
         hipLaunchKernelGGL((k_sf_dual_p<MODE, REDUCE>), grid_for((size_t)g.n * a.nf), block, 0, s, g, a);
     }
     hipLaunchKernelGGL((k_sf_dual_q<MODE, REDUCE>), grid_for((size_t)g.N), block, 0, s, g, a, a.ub);
@@ -254,19 +448,34 @@ hipError_t mmc_sf_launch_dual(const Geom &g, const SfArrays &a, int mode, bool r
     return hipGetLastError();
 }
 
-hipError_t mmc_sf_launch_primal(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s) {
+// frame groups of the tile scatter: enough workgroups to fill the GPU a few times over
+static int scatter_groups(const Geom &g, const SfArrays &a) {
+    const int want = (4096 + g.ntiles - 1) / g.ntiles;
+    return want < 1 ? 1 : (want > a.nf ? a.nf : want);
+}
+
+template <int MODE, bool REDUCE>
+static void launch_primal_mode(const Geom &g, const SfArrays &a, hipStream_t s) {
     const dim3 block(MMC_THREADS);
-    const size_t npix = (size_t)g.N * a.nf;
-    if (mode == MODE_STEPS) {
-        hipLaunchKernelGGL(k_sf_scatter<MODE_STEPS>, grid_for(npix), block, 0, s, g, a);
-        hipLaunchKernelGGL((k_sf_primal<MODE_STEPS, false>), grid_for((size_t)g.N), block, 0, s, g, a);
-    } else if (mode == MODE_RAW) {
-        hipLaunchKernelGGL(k_sf_scatter<MODE_RAW>, grid_for(npix), block, 0, s, g, a);
-        hipLaunchKernelGGL((k_sf_primal<MODE_RAW, false>), grid_for((size_t)g.N), block, 0, s, g, a);
-    } else {
-        hipLaunchKernelGGL(k_sf_scatter<MODE_UPDATE>, grid_for(npix), block, 0, s, g, a);
-        if (reduce) hipLaunchKernelGGL((k_sf_primal<MODE_UPDATE, true>), grid_for((size_t)g.N), block, 0, s, g, a);
-        else hipLaunchKernelGGL((k_sf_primal<MODE_UPDATE, false>), grid_for((size_t)g.N), block, 0, s, g, a);
-    }
+    const int ngroups = scatter_groups(g, a);
+    if (a.any_irregular) hipLaunchKernelGGL(k_sf_scatter<MODE>, grid_frames(g, a), block, 0, s, g, a);
+    if (MODE != MODE_STEPS && g.f == 4) hipLaunchKernelGGL(k_sf_atp4, dim3(g.ntiles, a.nf), block, 0, s, g, a);
+    else hipLaunchKernelGGL(k_sf_atp<MODE>, grid_frames(g, a), block, 0, s, g, a);
+    hipLaunchKernelGGL(k_sf_scatter_tile, dim3(g.ntiles, ngroups), block, 0, s, g, a, ngroups);
+    hipLaunchKernelGGL((k_sf_primal<MODE, REDUCE>), grid_for((size_t)g.N), block, 0, s, g, a);
+}
+
+hipError_t mmc_sf_launch_primal(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s) {
+    if (mode == MODE_STEPS) launch_primal_mode<MODE_STEPS, false>(g, a, s);
+    else if (mode == MODE_RAW) launch_primal_mode<MODE_RAW, false>(g, a, s);
+    else if (reduce) launch_primal_mode<MODE_UPDATE, true>(g, a, s);
+    else launch_primal_mode<MODE_UPDATE, false>(g, a, s);
+    return hipGetLastError();
+}
+
+hipError_t mmc_sf_launch_bbox(const Geom &g, const SfArrays &a, hipStream_t s) {
+    const int count = a.nf * g.ntiles * 4;
+    hipLaunchKernelGGL(k_sf_bbox_clear, grid_for((size_t)count), dim3(MMC_THREADS), 0, s, a.bbox, count);
+    hipLaunchKernelGGL(k_sf_bbox, grid_frames(g, a), dim3(MMC_THREADS), 0, s, g, a);
     return hipGetLastError();
 }

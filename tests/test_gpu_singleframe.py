@@ -70,6 +70,43 @@ def test_other_zoom_factor_and_ragged_frame():
         assert rel_l2(s.get_state(), sfo.image(P, x)) < 1e-4
 
 
+def test_violent_flow_and_outliers_take_the_global_scatter():
+    """Frames whose source rectangles are too large to walk per tile (random flow of +-12 px, a few
+    vectors of +-60 px) go through global atomics; the others through the tile kernel; mixed here."""
+    f, v, occ = make_sf_case(34, 16, 24, 5, flow_scale=1.0)
+    rng = np.random.default_rng(3)
+    v[:, :, 0, :] = rng.normal(0.0, 12.0, v[:, :, 0, :].shape)             # violent everywhere
+    out = rng.random(v[:, :, 4, 0].shape) < 0.002                          # outliers in an otherwise smooth frame
+    v[:, :, 4, 0][out] += 60.0
+    v[:, :, 4, 1][out] -= 40.0
+    v = v.astype(np.float32).astype(np.float64)
+    P = sfo.build_problem(f, v, alpha=0.1, k=K7)
+    x, _, _ = sfo.pdhg(P, 60)
+    rngy = np.random.default_rng(1)
+    with _solver(f, v) as s:
+        y = rngy.normal(size=P.K.shape[0])
+        m = P.n * P.nf
+        assert rel_l2(s.apply_KT(y[:m], y[m:]), P.KT @ y) < 1e-5
+        tau, _, _ = s.steps()
+        assert rel_l2(tau, P.T) < 1e-5
+        s.solve(60)
+        assert rel_l2(s.get_state(), sfo.image(P, x)) < 1e-4
+
+
+def test_window_too_large_for_lds_takes_the_scratch_plane():
+    """Zoom 8: the 16 x 16 low-resolution tile needs a 134 x 134 window, more than the fused dual kernel
+    stages; the two-kernel path through the scratch plane runs instead."""
+    f, v, _ = make_sf_case(35, 5, 6, 3, factor=8, flow_scale=2.0)
+    P = sfo.build_problem(f, v, factor=8, alpha=0.1, k=K7, sampling="stride")
+    x, _, _ = sfo.pdhg(P, 50)
+    with _solver(f, v, k=K7, sampling="stride", factor=8) as s:
+        u = np.random.default_rng(2).normal(size=(40, 48))
+        p, q = s.apply_K(u)
+        assert rel_l2(p, (P.K @ u.ravel(order="F"))[:P.n * P.nf]) < 1e-5
+        s.solve(50)
+        assert rel_l2(s.get_state(), sfo.image(P, x)) < 1e-4
+
+
 def test_start_point_tolerance_stop_and_reproducibility():
     f, v, _ = make_sf_case(32, 8, 8, 5)
     P = sfo.build_problem(f, v, alpha=0.1, k=K7)
