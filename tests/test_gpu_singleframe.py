@@ -46,7 +46,8 @@ def test_operators_adjoint_and_steps(flow, with_occ):
 
 
 @pytest.mark.parametrize("nf,delta,sampling,k", [(5, 0.0, "average", K7), (13, 0.01, "average", K7),
-                                                 (3, 0.0, "stride", K7), (4, 0.01, "average", None)])
+                                                 (3, 0.0, "stride", K7), (4, 0.01, "average", None),
+                                                 (1, 0.0, "average", K7), (2, 0.01, "average", K7)])
 def test_solve_parity(nf, delta, sampling, k):
     f, v, occ = make_sf_case(20 + nf, 8, 10, nf, flow_scale=1.5, with_occ=(nf == 5))
     P = sfo.build_problem(f, v, alpha=0.1, huber_eps=delta, k=k, sampling=sampling, occ=occ)
