@@ -374,7 +374,8 @@ int mmc_sf_set_blur(mmc_sf_handle *h, const float *k, int kh, int kw);
 int mmc_sf_set_flow(mmc_sf_handle *h, const float *v, const uint8_t *occ);
 /* Start point, Ny x Nx; NULL: zero (prost.variable(N) starts there, :97).  Duals start at zero. */
 int mmc_sf_set_state(mmc_sf_handle *h, const float *u);
-/* Masks and diagonal step sizes; needs low-res data and flow. */
+/* Source rectangles of the tile scatter and diagonal step sizes; needs low-res data and flow,
+ * leaves the iterate and the duals as they are.  Call again after mmc_sf_set_flow / mmc_sf_set_blur. */
 int mmc_sf_init(mmc_sf_handle *h);
 /* As mmc_solve: at most max_iters iterations (:86-92: 7500 'accurate', 2500 otherwise); tol > 0
  * stops on the relative change of the iterates, checked every check_every iterations. */

@@ -159,7 +159,7 @@ struct SfArrays {
 };
 // dual half-iteration: W_i ub, p and q updates; primal half-iteration: scatter and u update.
 // MODE_RAW applies K to ub (results in p, qx, qy) resp. K' to (p, q) (result in ub); MODE_STEPS
-// writes the dual steps to sigp, qx, qy resp. the primal steps to tau.
+// writes the dual steps of the data rows to sigp resp. the primal steps to tau and touches nothing else.
 hipError_t mmc_sf_launch_dual(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s);
 hipError_t mmc_sf_launch_primal(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s);
 // source rectangles of every (frame, tile) from the flows: a.bbox

@@ -212,16 +212,11 @@ extern "C" int mmc_sf_init(mmc_sf_handle *h) {
         SFHIP(h, hipMemcpyAsync(h->a.irregular, irr.data(), irr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         SFHIP(h, hipStreamSynchronize(h->stream));
     }
-    // step sizes: the operators applied to constant input (no entry of K is negative); the duals
-    // hold the dual steps for a moment and are cleared again
-    std::vector<float> keep_u((size_t)h->N), keep_ub((size_t)h->N);
-    SFHIP(h, hipMemcpyAsync(keep_ub.data(), h->a.ub, keep_ub.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    SFHIP(h, hipStreamSynchronize(h->stream));
+    // step sizes: the operators applied to constant input (no entry of K is negative).  These launches write
+    // sigp and tau only and leave the accumulator at zero; the iterate and the duals are not touched.
     SFHIP(h, hipMemsetAsync(h->a.acc, 0, (size_t)h->N * sizeof(unsigned long long), h->stream));
     SFHIP(h, mmc_sf_launch_dual(g, h->a, MODE_STEPS, false, h->stream));
     SFHIP(h, mmc_sf_launch_primal(g, h->a, MODE_STEPS, false, h->stream));
-    if ((rc = sf_zero_duals(h))) return rc;
-    SFHIP(h, hipMemcpyAsync(h->a.ub, keep_ub.data(), keep_ub.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     SFHIP(h, hipStreamSynchronize(h->stream));
     h->inited = true;
     return MMC_OK;

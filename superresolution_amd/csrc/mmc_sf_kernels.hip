@@ -157,16 +157,12 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_q(Geom g, SfArrays a, c
             // one step per isotropic group: 1 / (largest absolute row sum of the group)
             const float rs = fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f);
             const float sg = rs > 0.f ? 1.f / rs : 1.f;
-            if (MODE == MODE_STEPS) {
-                a.qx[j] = sg; a.qy[j] = sg;
-            } else {
-                const float ox = a.qx[j], oy = a.qy[j];
-                float nx = ox + sg * dx, ny = oy + sg * dy;
-                const float n2 = nx * nx + ny * ny;
-                if (n2 > a.alpha * a.alpha) { const float sc = a.alpha / sqrtf(n2); nx *= sc; ny *= sc; }
-                a.qx[j] = nx; a.qy[j] = ny;
-                if (REDUCE) { part[0] = (nx - ox) * (nx - ox) + (ny - oy) * (ny - oy); part[1] = nx * nx + ny * ny; }
-            }
+            const float ox = a.qx[j], oy = a.qy[j];
+            float nx = ox + sg * dx, ny = oy + sg * dy;
+            const float n2 = nx * nx + ny * ny;
+            if (n2 > a.alpha * a.alpha) { const float sc = a.alpha / sqrtf(n2); nx *= sc; ny *= sc; }
+            a.qx[j] = nx; a.qy[j] = ny;
+            if (REDUCE) { part[0] = (nx - ox) * (nx - ox) + (ny - oy) * (ny - oy); part[1] = nx * nx + ny * ny; }
         }
     }
     if (REDUCE) block_accumulate<2>(part, a.sums, 2);
@@ -437,7 +433,8 @@ static void launch_dual_mode(const Geom &g, const SfArrays &a, hipStream_t s) {
         hipLaunchKernelGGL(k_sf_warp<MODE>, grid_frames(g, a), block, 0, s, g, a, a.ub);
         hipLaunchKernelGGL((k_sf_dual_p<MODE, REDUCE>), grid_for((size_t)g.n * a.nf), block, 0, s, g, a);
     }
-    hipLaunchKernelGGL((k_sf_dual_q<MODE, REDUCE>), grid_for((size_t)g.N), block, 0, s, g, a, a.ub);
+    // the step of the gradient rows depends on the pixel position only; the update recomputes it
+    if (MODE != MODE_STEPS) hipLaunchKernelGGL((k_sf_dual_q<MODE, REDUCE>), grid_for((size_t)g.N), block, 0, s, g, a, a.ub);
 }
 
 hipError_t mmc_sf_launch_dual(const Geom &g, const SfArrays &a, int mode, bool reduce, hipStream_t s) {

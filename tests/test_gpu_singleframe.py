@@ -130,6 +130,18 @@ def test_start_point_tolerance_stop_and_reproducibility():
         assert sfo.primal_energy(P, s.get_state().ravel(order="F").astype(np.float64)) < e0
 
 
+def test_init_on_a_live_handle_keeps_iterate_and_duals():
+    """A second mmc_sf_init (needed after a new flow or blur) recomputes rectangles and steps only."""
+    f, v, _ = make_sf_case(36, 8, 8, 5)
+    P = sfo.build_problem(f, v, alpha=0.1, k=K7)
+    x, _, _ = sfo.pdhg(P, 60)
+    with _solver(f, v) as s:
+        s.solve(30)
+        s.init()
+        s.solve(30)
+        assert rel_l2(s.get_state(), sfo.image(P, x)) < 1e-4
+
+
 def test_mirror_function_colour_and_grey():
     from superresolution_amd.singleframe import singleframeMotionSR
     from superresolution_amd.mmc import rgb2ycbcr
