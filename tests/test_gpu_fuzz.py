@@ -1,0 +1,19 @@
+"""Random small configurations of both solves against the scipy oracles (tools/fuzz_shapes.py):
+frames from 1 x 1 low-resolution pixels to several tiles, zoom factors 1..5, 1..4 frames, every model
+and flow direction, masks, blur kernels 1x1..7x7 or none; 25 iterations, relative L2 <= 1e-4."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_small_configurations(seed):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shapes.py"), "150", str(seed)],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "misses 0" in res.stdout
