@@ -14,7 +14,7 @@ from superresolution_amd.solver import FrameBlockSolver
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 L, ny, nx = 30, 270, 480
 blk = synthetic.make_block(ny, nx, L, 0, L, device="cpu")
-f, v = np.ascontiguousarray(blk["f"]), np.ascontiguousarray(blk["v"])
+f, v = np.asfortranarray(blk["f"], dtype=np.float32), np.asfortranarray(blk["v"], dtype=np.float32)   # column-major float32, what a MATLAB gateway hands over
 k = synthetic.gaussian_kernel()
 t = {}
 for rep in range(2):           # the second repetition is reported (first: library load, allocator warm-up)
