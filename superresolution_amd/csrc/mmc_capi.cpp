@@ -6,6 +6,9 @@
 #include "mmc_internal.h"
 
 #include <algorithm>
+#include <array>
+#include <map>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -119,7 +122,10 @@ extern "C" const char *mmc_last_error(const mmc_handle *h) {
 // The probe ranks shifts as the sweeps do where they differ by several per cent (2160-row frames);
 // differences of about one per cent between its timings do not carry over to the sweeps (1080-row
 // frames: the default is the sweeps' optimum, the probe is flat), so the default stays unless a
-// candidate beats it by PLANE_PROBE_MARGIN.
+// candidate beats it by PLANE_PROBE_MARGIN.  The choice is kept per frame size and device (g_skew_cache).
+static std::mutex g_skew_mutex;
+static std::map<std::array<int, 4>, size_t> g_skew_cache;     // (Ny, Nx, probed frames, device) -> chosen shift
+
 static_assert(((size_t)64 << 10) + PLANE_SKEW_DEFAULT_STEP * ((size_t)32 << 10) == PLANE_SKEW_DEFAULT, "default shift must be a probe candidate");
 static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, size_t *skew) {
     const Geom &g = h->g;
@@ -127,6 +133,14 @@ static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, siz
     if (const char *e = getenv("MMC_PLANE_SKEW")) { *skew = std::min((size_t)atol(e) & ~(size_t)255, (size_t)PLANE_SKEW_MAX); return MMC_OK; }
     const size_t plane_bytes = frame_slots(h) * (size_t)g.N * sizeof(float);
     if (plane_bytes < ((size_t)64 << 20) || g.Ny % 4 != 0 || raw.size() < 12) return MMC_OK;
+    // one probe per frame size and device in a process: the blocks of a group share its result
+    const int nprobe = std::min(h->L, (int)PLANE_PROBE_FRAMES);
+    const std::array<int, 4> key = {g.Ny, g.Nx, nprobe, h->prm.device};
+    {
+        std::lock_guard<std::mutex> lock(g_skew_mutex);
+        auto it = g_skew_cache.find(key);
+        if (it != g_skew_cache.end() && !getenv("MMC_PROBE_TRACE")) { *skew = it->second; return MMC_OK; }
+    }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
@@ -174,6 +188,10 @@ static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, siz
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    if (rc == MMC_OK) {
+        std::lock_guard<std::mutex> lock(g_skew_mutex);
+        g_skew_cache[key] = *skew;
+    }
     return rc;
 }
 
