@@ -7,6 +7,11 @@
  *   problem assembly   init_u_prost            MultiframeMotionCoupling.m:346-574
  *   the solve          solveU                  MultiframeMotionCoupling.m:977-1004
  * All operators are matrix-free; nothing here builds a sparse matrix.
+ * Three groups of entry points:
+ *   mmc_*        one frame block on one GPU (a whole sequence is the block [0, nc))
+ *   mmc_group_*  one sequence as several blocks, one per GPU, driven by the calling thread
+ *   mmc_sf_*     the reference's comparison methods: one high-resolution frame with
+ *                motion-compensated data terms (classical methods/singleframeMotionSR_*_prost.m)
  *
  * Conventions
  *   - Plain C, no C++ types.  Every function returns MMC_OK (0) or a negative
