@@ -155,6 +155,8 @@ struct SfArrays {
                                  //      the frame is scattered with global atomics instead
     int any_irregular;
     const float *cker, *cA;      // composite kernel CH x CW and absolute column sums of D*B (of the geometry handle)
+    float *ck12;                 // the composite kernel zero-padded to 12 x 12 (zoom 4, kernels up to 12 x 12), else unused
+    int ck12_ok;
     double *sums;                // [MMC_NUM_SUMS_INT][MMC_SUM_SLOTS]
 };
 // dual half-iteration: W_i ub, p and q updates; primal half-iteration: scatter and u update.

@@ -110,7 +110,7 @@ extern "C" int mmc_sf_create(const mmc_sf_params *p, mmc_sf_handle **out) {
         (rc = sf_alloc(h, &a.vx, nf * N)) || (rc = sf_alloc(h, &a.vy, nf * N)) || (rc = sf_alloc(h, &a.wimg, nf * N)) ||
         (rc = sf_alloc(h, &a.p, nf * n)) || (rc = sf_alloc(h, &a.f, nf * n)) || (rc = sf_alloc(h, &a.sigp, nf * n)) ||
         (rc = sf_alloc(h, &a.tau, N)) || (rc = sf_alloc(h, &a.acc, N)) ||
-        (rc = sf_alloc(h, &a.bbox, nf * (size_t)g.ntiles * 4)) || (rc = sf_alloc(h, &a.irregular, nf)) ||
+        (rc = sf_alloc(h, &a.ck12, (size_t)144)) || (rc = sf_alloc(h, &a.bbox, nf * (size_t)g.ntiles * 4)) || (rc = sf_alloc(h, &a.irregular, nf)) ||
         (rc = sf_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)))
         return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(sfail(h, MMC_ERR_HIP, "hipStreamSynchronize failed"));
@@ -197,6 +197,17 @@ extern "C" int mmc_sf_init(mmc_sf_handle *h) {
     const Arrays &ga = *mmc_internal_arrays(h->geo);
     h->a.cker = ga.cker;
     h->a.cA = ga.cA;
+    h->a.ck12_ok = 0;
+    if (g.f == 4 && g.CH <= 12 && g.CW <= 12) {
+        std::vector<float> ck((size_t)g.CH * g.CW), pad(144, 0.f);
+        SFHIP(h, hipMemcpyAsync(ck.data(), ga.cker, ck.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        SFHIP(h, hipStreamSynchronize(h->stream));
+        for (int nn = 0; nn < g.CW; ++nn)
+            for (int mm = 0; mm < g.CH; ++mm) pad[(size_t)mm + 12 * (size_t)nn] = ck[(size_t)mm + (size_t)g.CH * nn];
+        SFHIP(h, hipMemcpyAsync(h->a.ck12, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        SFHIP(h, hipStreamSynchronize(h->stream));
+        h->a.ck12_ok = 1;
+    }
     // source rectangles of the tile scatter; a frame with a rectangle too large to walk is scattered with global atomics
     {
         SFHIP(h, mmc_sf_launch_bbox(g, h->a, h->stream));

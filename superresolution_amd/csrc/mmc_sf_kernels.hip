@@ -278,45 +278,71 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_atp(Geom g, SfArrays a) {
     a.wimg[idx] = sf_z<MODE>(g, a, i, r, c, j);
 }
 
-// The same at zoom 4 with wave-uniform kernel phases: a workgroup takes a 64 x 16 tile of frame i in 16
-// passes of 64 pixels that share (row mod 4, column mod 4), one pass per (wave, step).  The kernel entry of a
-// tap then depends on the pass only (scalar loads, uniform bounds), the low-resolution rows of the 64 lanes
-// are consecutive, and what is left per pixel is Jr x Jc loads of p and as many multiply-adds.
+// The same at zoom 4, the way the primal sweep of mmc_kernels.hip forms A'p: the workgroup stages the
+// low-resolution window of p_i under its 64 x 16 tile in LDS (zero outside the frame, so the sums need no
+// masks), each thread owns four consecutive rows of one column, and the columns of a wave are taken 4
+// apart, so that the kernel phase of every tap is wave-uniform: weights are scalar loads, the values of p
+// are LDS reads at lane base + uniform offset.  Pixels on the frame border take the general gather.
+// J3: kernels up to 12 x 12, taken from the table zero-padded to 12 x 12 (a.ck12): the 3 x 3 taps per row are
+// unrolled without bounds, their weights are scalar loads at constant offsets.
+template <bool J3>
 __global__ __launch_bounds__(MMC_THREADS) void k_sf_atp4(Geom g, SfArrays a) {
+    extern __shared__ __align__(16) float pl[];
+    const int Jr = J3 ? 3 : g.Jr, Jc = J3 ? 3 : g.Jc;
     const int i = blockIdx.y, tile = blockIdx.x;
     if (a.irregular[i]) return;
     const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
     const int r0 = tr * TILE_R, c0 = tc * TILE_C;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const float *p = a.p + (size_t)i * g.n;
     float *z = a.wimg + (size_t)i * g.N;
-    for (int step = 0; step < 4; ++step) {
-        const int phase = wave * 4 + step, pr = phase & 3, pc = phase >> 2;
-        const int r = r0 + 4 * (lane & 15) + pr, c = c0 + 4 * (lane >> 4) + pc;
-        if (r >= g.Ny || c >= g.Nx) continue;
-        const int j = r + g.Ny * c;
-        if (r == 0 || r == g.Ny - 1 || c == 0 || c == g.Nx - 1) { z[j] = gather_ATp(g, a.cker, p, r, c); continue; }
-        // x = r - oy, y = c - ox: phases and the first low-resolution row / column of lane 0 are uniform
-        const int xb = r0 + pr - g.oy, yb = c0 + pc - g.ox;
-        const int m0 = xb & 3, n0 = yb & 3;
-        const int R0 = (xb >> 2) + (lane & 15), C0 = (yb >> 2) + (lane >> 4);
-        float acc = 0.f;
+    // low-resolution rows / columns with a kernel row / column on the tile (oy, ox <= 0)
+    const int Rlo = ((r0 - g.oy) >> 2) - (Jr - 1), Rhi = (r0 + TILE_R - 1 - g.oy) >> 2;
+    const int Clo = ((c0 - g.ox) >> 2) - (Jc - 1), Chi = (c0 + TILE_C - 1 - g.ox) >> 2;
+    const int PR = Rhi - Rlo + 1, PC = Chi - Clo + 1;
+    const float inv_pr = 1.f / (float)PR;
+    for (int k = threadIdx.x; k < PR * PC; k += MMC_THREADS) {
+        int kc, kr;
+        divmod_small(k, PR, inv_pr, kc, kr);
+        const int R = Rlo + kr, C = Clo + kc;
+        pl[k] = (R >= 0 && R < g.ny && C >= 0 && C < g.nx) ? p[R + g.ny * C] : 0.f;
+    }
+    __syncthreads();
+    const int rq = threadIdx.x & 15, cg = (threadIdx.x >> 4) & 3, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = r0 + 4 * rq, c = c0 + 4 * cg + wave;
+    if (r >= g.Ny || c >= g.Nx) return;
+    const int yb = c0 + wave - g.ox;                           // uniform part of y = c - ox
+    const int n0 = yb & 3, Cl = cg + (yb >> 2) - Clo;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int xb = r0 + q - g.oy;                          // uniform part of x = r + q - oy
+        const int m0 = xb & 3;
+        const float *pq = pl + rq + (xb >> 2) - Rlo + PR * Cl;
+        if (J3) {
+            const float *ck = a.ck12 + m0 + 12 * n0;
+#pragma unroll
+            for (int jc = 0; jc < 3; ++jc)
+#pragma unroll
+                for (int jr = 0; jr < 3; ++jr) acc[q] += ck[4 * jr + 48 * jc] * pq[-jr - PR * jc];
+            continue;
+        }
         for (int jc = 0; jc < g.Jc; ++jc) {
             const int nn = n0 + 4 * jc;
             if (nn >= g.CW) break;
-            const int C = C0 - jc;
-            const bool okc = C >= 0 && C < g.nx;
-            const float *pcol = p + g.ny * min(max(C, 0), g.nx - 1);
             for (int jr = 0; jr < g.Jr; ++jr) {
                 const int mm = m0 + 4 * jr;
                 if (mm >= g.CH) break;
-                const float wgt = a.cker[mm + g.CH * nn];
-                const int R = R0 - jr;
-                const float t = wgt * pcol[min(max(R, 0), g.ny - 1)];
-                acc += (okc && R >= 0 && R < g.ny) ? t : 0.f;
+                acc[q] += a.cker[mm + g.CH * nn] * pq[-jr - PR * jc];
             }
         }
-        z[j] = acc;
+    }
+    const int j = r + g.Ny * c;
+    const bool cborder = c == 0 || c == g.Nx - 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (r + q >= g.Ny) break;
+        if (cborder || r + q == 0 || r + q == g.Ny - 1) acc[q] = gather_ATp(g, a.cker, p, r + q, c);
+        z[j + q] = acc[q];
     }
 }
 
@@ -456,7 +482,12 @@ static void launch_primal_mode(const Geom &g, const SfArrays &a, hipStream_t s) 
     const dim3 block(MMC_THREADS);
     const int ngroups = scatter_groups(g, a);
     if (a.any_irregular) hipLaunchKernelGGL(k_sf_scatter<MODE>, grid_frames(g, a), block, 0, s, g, a);
-    if (MODE != MODE_STEPS && g.f == 4) hipLaunchKernelGGL(k_sf_atp4, dim3(g.ntiles, a.nf), block, 0, s, g, a);
+    if (MODE != MODE_STEPS && g.f == 4) {
+        const int Jr = a.ck12_ok ? 3 : g.Jr, Jc = a.ck12_ok ? 3 : g.Jc;
+        const size_t lds = (size_t)(TILE_R / 4 + Jr + 1) * (TILE_C / 4 + Jc + 1) * sizeof(float);
+        if (a.ck12_ok) hipLaunchKernelGGL(k_sf_atp4<true>, dim3(g.ntiles, a.nf), block, lds, s, g, a);
+        else hipLaunchKernelGGL(k_sf_atp4<false>, dim3(g.ntiles, a.nf), block, lds, s, g, a);
+    }
     else hipLaunchKernelGGL(k_sf_atp<MODE>, grid_frames(g, a), block, 0, s, g, a);
     hipLaunchKernelGGL(k_sf_scatter_tile, dim3(g.ntiles, ngroups), block, 0, s, g, a, ngroups);
     hipLaunchKernelGGL((k_sf_primal<MODE, REDUCE>), grid_for((size_t)g.N), block, 0, s, g, a);
