@@ -104,15 +104,32 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_tile(Geom g, SfArrays a
     const float *vx = a.vx + (size_t)i * g.N, *vy = a.vy + (size_t)i * g.N;
     for (int k = threadIdx.x; k < g.CH * g.CW; k += MMC_THREADS) ck[k] = a.cker[k];
     const float inv_sr = 1.f / (float)SR;
-    for (int k = threadIdx.x; k < SR * SC; k += MMC_THREADS) {
-        int kc, kr;
-        divmod_small(k, SR, inv_sr, kc, kr);
-        const int r = min(max(wr0 + kr, 0), g.Ny - 1), c = min(max(wc0 + kc, 0), g.Nx - 1);
-        const int j = r + g.Ny * c;
-        const Taps tp = make_taps(g, r, c, vx[j], vy[j]);
-        float out = 0.f;
-        if (tp.valid) out = MODE == MODE_STEPS ? 1.f : sample(tp, img);
-        win[k] = out;
+    // four window pixels per thread and pass: their flow loads are issued together, then their gathers
+    for (int kb = threadIdx.x; kb < SR * SC; kb += 4 * MMC_THREADS) {
+        int rr[4], cc[4];
+        float fx[4], fy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(kb + u * MMC_THREADS, SR * SC - 1);
+            int kc, kr;
+            divmod_small(k, SR, inv_sr, kc, kr);
+            rr[u] = min(max(wr0 + kr, 0), g.Ny - 1);
+            cc[u] = min(max(wc0 + kc, 0), g.Nx - 1);
+            const int j = rr[u] + g.Ny * cc[u];
+            fx[u] = vx[j]; fy[u] = vy[j];
+        }
+        float out[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const Taps tp = make_taps(g, rr[u], cc[u], fx[u], fy[u]);       // invalid taps point at pixel 0
+            const float v = MODE == MODE_STEPS ? 1.f : sample(tp, img);
+            out[u] = tp.valid ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kb + u * MMC_THREADS;
+            if (k < SR * SC) win[k] = out[u];
+        }
     }
     __syncthreads();
     float part[2] = {0.f, 0.f};
