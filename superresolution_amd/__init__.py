@@ -8,7 +8,7 @@ library has not been built.
 from ._capi import MMCError  # noqa: F401
 
 __all__ = ["MMCError", "FrameBlockSolver", "SequenceGroupSolver", "MultiframeMotionCoupling", "MultiframeMotionCouplingAlternating",
-           "SingleFrameSolver", "singleframeMotionSR"]
+           "SingleFrameSolver", "singleframeMotionSR", "LoadImSequence", "LoadImSequenceForward", "LoadImSequenceReal"]
 
 
 def __getattr__(name):
@@ -27,4 +27,7 @@ def __getattr__(name):
     if name in ("SingleFrameSolver", "singleframeMotionSR"):
         from . import singleframe
         return getattr(singleframe, name)
+    if name in ("LoadImSequence", "LoadImSequenceForward", "LoadImSequenceReal"):
+        from . import loaders
+        return getattr(loaders, name)
     raise AttributeError(name)
