@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--kappa", type=float, default=0.25)
     ap.add_argument("--flow", default="rigid", choices=["rigid", "smooth", "outliers"],
                     help="flow field of the headline run (see synthetic.perturb_flows)")
+    ap.add_argument("--direction", default="backward", choices=["forward", "backward", "forward-backward"],
+                    help="flowDirection of the coupling operator (the same synthetic flow field is used for all three: "
+                         "other directions time the other pair layouts, their images mean nothing)")
     ap.add_argument("--extra-flows", default="smooth,outliers",
                     help="comma list of further flow kinds timed after the headline run at N=1 (extra keys only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -242,7 +245,7 @@ def main():
     u_up = upsample_sequence(blk["f_state"], factor).astype(np.float32)
     stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
     s = FrameBlockSolver(ny, nx, factor, nc, begin, end, alpha=0.01, kappa=args.kappa, h=0.0,
-                         flow_direction="backward", sampling="average", device=local_rank, stream=stream)
+                         flow_direction=args.direction, sampling="average", device=local_rank, stream=stream)
     s.set_lowres(blk["f"])
     s.set_blur(synthetic.gaussian_kernel())
     s.set_flow(blk["v"])
@@ -334,9 +337,9 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic sequence, %d HR frames of %dx%d (LR %dx%d, zoom 4), %d on rank 0, "
-                                   "%s model kappa=%g, alpha=0.01, backward flow (%s), gaussian(7,sqrt(0.6)) blur + 4x4 mean"
+                                   "%s model kappa=%g, alpha=0.01, %s flow (%s), gaussian(7,sqrt(0.6)) blur + 4x4 mean"
                                    % (nc, Ny, Nx, ny, nx, L, "infimal-convolution" if model == "ic" else "single-primal",
-                                      args.kappa, args.flow),
+                                      args.kappa, args.direction, args.flow),
                        "frames_total": nc, "hr_pixels_total": M_total, "parallelism": "frame-block x%d" % world,
                        "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
                        "plane_skew_bytes": s.plane_skew},

@@ -7,3 +7,5 @@ run --kappa 1
 run --kappa nan
 run --flow smooth
 run --flow outliers
+run --direction forward
+run --direction forward-backward
