@@ -8,7 +8,7 @@ library has not been built.
 from ._capi import MMCError  # noqa: F401
 
 __all__ = ["MMCError", "FrameBlockSolver", "SequenceGroupSolver", "MultiframeMotionCoupling", "MultiframeMotionCouplingAlternating",
-           "SingleFrameSolver", "singleframeMotionSR", "LoadImSequence", "LoadImSequenceForward", "LoadImSequenceReal"]
+           "SingleFrameSolver", "singleframeMotionSR", "LoadImSequence", "LoadImSequenceForward", "LoadImSequenceReal", "readFlowFile", "writeFlowFile"]
 
 
 def __getattr__(name):
@@ -30,4 +30,7 @@ def __getattr__(name):
     if name in ("LoadImSequence", "LoadImSequenceForward", "LoadImSequenceReal"):
         from . import loaders
         return getattr(loaders, name)
+    if name in ("readFlowFile", "writeFlowFile"):
+        from . import flowio
+        return getattr(flowio, name)
     raise AttributeError(name)

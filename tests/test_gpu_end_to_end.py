@@ -288,3 +288,56 @@ def test_flexbox_backward_terms_as_written():
         results[as_written] = m.result2.copy()
         m.close()
     assert np.abs(results[True] - results[False]).max() > 1e-3          # the two models do differ
+
+
+def test_script_sequence_from_files(tmp_path):
+    """The call sequence of variants/testfile_gt_sintel.m with every input read from files: frames
+    through LoadImSequence (:28), ground-truth flows from .flo files (:33-39), occlusion maps from
+    images (:42-46, handed over as maps where the script prebuilds a sparse warpOp), then init / run
+    and the error margin of the central frame (:99-103)."""
+    PIL = pytest.importorskip("PIL.Image")
+    from scipy import ndimage
+    from superresolution_amd import flowio, loaders, metrics
+    from superresolution_amd.mmc import MultiframeMotionCoupling, rgb2ycbcr
+    rng = np.random.default_rng(21)
+    Ny, Nx, nf, d = 96, 128, 5, (0.75, -0.5)                       # d = (along columns, along rows) per frame
+    base = ndimage.gaussian_filter(rng.random((Ny + 40, Nx + 40, 3)), (1.2, 1.2, 0))
+    base = (base - base.min()) / (base.max() - base.min())
+    frames_dir, flow_dir, occ_dir = tmp_path / "video", tmp_path / "flow", tmp_path / "occ"
+    for p in (frames_dir, flow_dir, occ_dir):
+        p.mkdir()
+    for t in range(nf):
+        img = ndimage.shift(base, (t * d[1], t * d[0], 0), order=3, mode="nearest")[20:20 + Ny, 20:20 + Nx]
+        PIL.fromarray(np.clip(np.round(img * 255), 0, 255).astype(np.uint8)).save(str(frames_dir / ("frame_%04d.png" % (t + 1))))
+    occ_true = np.zeros((Ny, Nx, nf - 1), dtype=bool)
+    for t in range(nf - 1):
+        flowio.writeFlowFile(np.stack([np.full((Ny, Nx), d[0]), np.full((Ny, Nx), d[1])], axis=2), str(flow_dir / ("frame_%04d.flo" % (t + 1))))
+        occ_true[10 + 3 * t:20 + 3 * t, 30:50, t] = True
+        PIL.fromarray((occ_true[:, :, t] * 255).astype(np.uint8)).save(str(occ_dir / ("frame_%04d.png" % (t + 1))))
+
+    small, large = loaders.LoadImSequence(str(frames_dir), 1, nf, 4, "bicubic")
+    v = flowio.load_flow_sequence(str(flow_dir), nf - 1)
+    occ = flowio.load_occlusion_sequence(str(occ_dir), nf - 1)
+    assert small.shape == (Ny // 4, Nx // 4, 3, nf) and v.shape == (Ny, Nx, nf - 1, 2) and np.array_equal(occ, occ_true)
+
+    m = MultiframeMotionCoupling(small, flowField=v, occlusion=occ, verbose=0)
+    m.kappa = 0.5                                                  # :79
+    m.k = KBLUR
+    m.init()
+    m._opts.update(max_iters=80, tol=0.0)                          # equal iteration count for the comparison below
+    m.run()
+    y_small = np.stack([rgb2ycbcr(small[:, :, :, i])[:, :, 0] for i in range(nf)], axis=2)
+    P = orc.build_problem(y_small, v, kappa=0.5, k=KBLUR, occ=occ)
+    x, _, _ = orc.pdhg(P, 80)
+    u_ref, w_ref = orc.split_primal(P, x)
+    assert abs(m.h - P.h) < 1e-5 * P.h
+    assert rel_l2(m._u, u_ref) < 1e-4 and rel_l2(m._w, w_ref) < 1e-3
+    assert m.result1.shape == (Ny, Nx, 3, nf)
+    m._opts.update(max_iters=1500, tol=1e-5)                       # the solver keeps its state: the solve goes on
+    m.run()
+    psnr_sr, ssim_sr = metrics.error_margin(m.result1, large)
+    up = np.stack([np.clip(loaders.imresize(small[:, :, :, i], 4.0), 0, 1) for i in range(nf)], axis=3)
+    psnr_up, ssim_up = metrics.error_margin(up, large)
+    print("PSNR %.2f dB (bicubic %.2f), SSIM %.3f (bicubic %.3f)" % (psnr_sr, psnr_up, ssim_sr, ssim_up))
+    assert psnr_sr > psnr_up + 0.3 and ssim_sr > ssim_up + 0.02
+    m.close()
