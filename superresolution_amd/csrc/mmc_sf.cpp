@@ -77,6 +77,7 @@ extern "C" int mmc_sf_create(const mmc_sf_params *p, mmc_sf_handle **out) {
     if (p->size != sizeof(mmc_sf_params) || p->version != MMC_ABI_VERSION)
         return sfail(nullptr, MMC_ERR_INVALID_ARG, "mmc_sf_create: params size/version mismatch");
     if (p->num_frames <= 0) return sfail(nullptr, MMC_ERR_INVALID_ARG, "mmc_sf_create: need at least one low-resolution frame");
+    if (p->num_frames > 65535) return sfail(nullptr, MMC_ERR_INVALID_ARG, "mmc_sf_create: more than 65535 frames (a grid dimension of the per-frame kernels)");
     if (!(p->huber_eps >= 0.f)) return sfail(nullptr, MMC_ERR_INVALID_ARG, "mmc_sf_create: huber_eps must be >= 0");
     if (p->sampling != MMC_SAMPLING_AVERAGE && p->sampling != MMC_SAMPLING_STRIDE)
         return sfail(nullptr, MMC_ERR_UNSUPPORTED, "mmc_sf_create: the single-frame solve takes the built-in samplers only ('average' at factor 4, 'stride')");

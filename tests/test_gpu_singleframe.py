@@ -166,6 +166,8 @@ def test_argument_errors():
     from superresolution_amd.singleframe import SingleFrameSolver
     with pytest.raises(MMCError):
         SingleFrameSolver(8, 8, 4, 0)
+    with pytest.raises(MMCError, match="65535"):
+        SingleFrameSolver(8, 8, 4, 70000)
     with pytest.raises(MMCError):
         SingleFrameSolver(8, 8, 4, 3, huber_eps=-1.0)
     with pytest.raises(MMCError):
