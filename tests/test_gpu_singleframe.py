@@ -212,3 +212,62 @@ def test_city_size_13_frames_against_the_oracle():
         st = s.solve(300, 0.0, 100)
         e330 = sfo.primal_energy(P, s.get_state().ravel(order="F").astype(np.float64))
         assert e330 < e30 and st["res_primal"] < 5e-3
+
+
+def test_full_hd_13_frames_properties():
+    """1080 x 1920 x 13, the largest size tools/bench_singleframe.py times, where the scipy oracle is too slow:
+    properties that do not depend on the size.  <K u, y> = <u, K' y> for random u, y; the steps are the
+    reciprocal absolute row and column sums, i.e. K 1 and K' 1 (no entry of the data rows is negative);
+    the primal energy sum_i H_delta(D B W_i u - f_i) + alpha TV(u), formed on the host from K u, falls;
+    two runs agree bit for bit."""
+    from superresolution_amd import synthetic
+    from helpers import smooth_field
+    ny, nx, nf = 270, 480, 13
+    Ny, Nx = 4 * ny, 4 * nx
+    N, n = Ny * Nx, ny * nx
+    blk = synthetic.make_block(ny, nx, nf, 0, nf, device="cpu")
+    f = np.asarray(blk["f"], dtype=np.float32)
+    rng = np.random.default_rng(17)
+    cs = sfo.central_slice(nf)
+    v = np.zeros((Ny, Nx, nf, 2), dtype=np.float32)
+    for i in range(nf):
+        v[:, :, i, 0] = 0.7 * (i - cs) + smooth_field(rng, (Ny, Nx), 0.3)
+        v[:, :, i, 1] = -0.4 * (i - cs) + smooth_field(rng, (Ny, Nx), 0.3)
+    alpha, delta = 0.1, 0.01
+    fvec = np.concatenate([f[:, :, i].ravel(order="F") for i in range(nf)]).astype(np.float64)
+
+    def energy(s, u):
+        p, q = s.apply_K(u)
+        r = np.abs(p.astype(np.float64) - fvec)
+        data = np.where(r <= delta, r * r / (2 * delta), r - delta / 2).sum()
+        g = q.astype(np.float64).reshape(2, N)
+        return data + alpha * np.sqrt((g * g).sum(axis=0)).sum()
+
+    with _solver(f, v, alpha=alpha, delta=delta) as s:
+        u = rng.standard_normal(N).astype(np.float32)
+        yp = rng.standard_normal(nf * n).astype(np.float32)
+        yq = rng.standard_normal(2 * N).astype(np.float32)
+        Kp, Kq = s.apply_K(u)
+        KTy = s.apply_KT(yp, yq)
+        lhs = np.dot(Kp.astype(np.float64), yp) + np.dot(Kq.astype(np.float64), yq)
+        rhs = np.dot(u.astype(np.float64), KTy)
+        assert abs(lhs - rhs) < 1e-5 * (np.linalg.norm(Kp) * np.linalg.norm(yp) + np.linalg.norm(Kq) * np.linalg.norm(yq))
+        tau, sp, sq = s.steps()
+        ones_p, _ = s.apply_K(np.ones(N, dtype=np.float32))
+        rows = np.where(ones_p > 0, 1.0 / np.where(ones_p > 0, ones_p, 1.0), 1.0)
+        assert np.abs(sp - rows).max() < 1e-5
+        cols = s.apply_KT(np.ones(nf * n, dtype=np.float32), np.zeros(2 * N, dtype=np.float32)).reshape((Ny, Nx), order="F")
+        cc, rr = np.meshgrid(np.arange(Nx), np.arange(Ny))
+        cols = cols + (cc > 0) + (cc < Nx - 1) + (rr > 0) + (rr < Ny - 1)       # the gradient's column sums
+        assert np.abs(tau.reshape((Ny, Nx), order="F") * cols - 1.0).max() < 1e-5
+        s.set_state(None)
+        e0 = energy(s, s.get_state())
+        s.solve(60)
+        u60 = s.get_state()
+        e60 = energy(s, u60)
+        st = s.solve(240, 0.0, 120)
+        e300 = energy(s, s.get_state())
+        assert e300 < e60 < e0 and st["res_primal"] < 1e-2
+        s.set_state(None)
+        s.solve(60)
+        assert np.array_equal(s.get_state(), u60)
