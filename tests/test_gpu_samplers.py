@@ -126,3 +126,40 @@ def test_taps_are_validated():
     with pytest.raises(MMCError):
         s2.set_sampling_taps(first, w, first, w)
     s2.close()
+
+
+@pytest.mark.parametrize("method,aa,k", [("bicubic", True, KBLUR), ("lanczos3", False, None)])
+def test_full_hd_adjoint_and_run(method, aa, k):
+    """1080 x 1920 frames with a sampler handed over as rows (interior taps as a composite kernel, the
+    deviating border rows as a sparse correction with some ten thousand entries): <K x, y> = <x, K' y> for
+    random x, y, which holds whatever the size; then a few iterations stay finite and move the iterate."""
+    from superresolution_amd import synthetic
+    from superresolution_amd.sampling import dim1_taps
+    from superresolution_amd.solver import FrameBlockSolver
+    ny, nx, nc = 270, 480, 2
+    Ny, Nx = 4 * ny, 4 * nx
+    blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
+    s = FrameBlockSolver(ny, nx, 4, nc, sampling="taps")
+    fy, wy = dim1_taps(Ny, ny, method, None, aa)
+    fx, wx = dim1_taps(Nx, nx, method, None, aa)
+    s.set_sampling_taps(fy, wy, fx, wx)
+    s.set_lowres(blk["f"]); s.set_blur(k); s.set_flow(blk["v"]); s.set_state(); s.init()
+    rng = np.random.default_rng(2)
+    u = rng.standard_normal((Ny, Nx, nc)).astype(np.float32)
+    w = rng.standard_normal((Ny, Nx, nc)).astype(np.float32)
+    Kp, Kg1, Kg2 = s.debug_apply_K(u, w)
+    yp = rng.standard_normal(Kp.size).astype(np.float32)
+    y1 = rng.standard_normal(Kg1.size).astype(np.float32)
+    y2 = rng.standard_normal(Kg2.size).astype(np.float32)
+    ku, kw = s.debug_apply_KT(yp, y1, y2)
+    d = lambda a, b: float(np.dot(a.astype(np.float64).ravel(order="F"), b.astype(np.float64).ravel(order="F")))
+    lhs = d(Kp, yp) + d(Kg1, y1) + d(Kg2, y2)
+    rhs = d(u, ku) + d(w, kw)
+    scale = sum(np.linalg.norm(a) * np.linalg.norm(b) for a, b in ((Kp, yp), (Kg1, y1), (Kg2, y2)))
+    assert abs(lhs - rhs) < 1e-5 * scale
+    u0, _ = s.get_state()
+    st = s.solve(10, 0.0, 10)
+    u1, w1 = s.get_state()
+    assert np.isfinite(u1).all() and np.isfinite(w1).all() and 0 < st["res_primal"] < 1.0
+    assert float(np.abs(u1 - u0).max()) > 1e-4
+    s.close()
