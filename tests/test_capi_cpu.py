@@ -148,3 +148,35 @@ def test_mex_gateway_type_checks_against_the_header():
         subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
                         "-I", os.path.join(ROOT, "tests", "mex_stub"), "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "mex", src)], check=True)
+
+
+def _sf_params(**kw):
+    p = _capi.mmc_sf_params()
+    p.size = C.sizeof(_capi.mmc_sf_params)
+    p.version = _capi.MMC_ABI_VERSION
+    p.ny, p.nx, p.factor, p.num_frames = 8, 8, 4, 5
+    p.alpha, p.huber_eps, p.sampling, p.device = 0.1, 0.0, 0, 0
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+@pytest.mark.parametrize("kw,status,text", [
+    ({"size": 8}, -1, "size/version"),
+    ({"num_frames": 0}, -1, "at least one low-resolution frame"),
+    ({"num_frames": 70000}, -1, "65535"),
+    ({"huber_eps": -0.5}, -1, "huber_eps"),
+    ({"sampling": 2}, -4, "built-in samplers"),
+    ({"factor": 0}, -1, "Input must be > 0"),                 # through the geometry handle, as mmc_create
+    ({"factor": 3}, -4, "factor 4"),
+])
+def test_single_frame_create_rejects_bad_parameters(kw, status, text):
+    """mmc_sf_create validates before it touches a GPU (classical methods/singleframeMotionSR_mitzel_prost.m
+    takes any frame count on paper but only builds 5 or 13 data terms, :101-123; here any count from 1 up)."""
+    lib = _capi.load_library()
+    h = C.c_void_p()
+    p = _sf_params(**kw)
+    rc = lib.mmc_sf_create(C.byref(p), C.byref(h))
+    assert rc == status and not h.value
+    assert text in lib.mmc_sf_last_error(None).decode()
+    assert lib.mmc_sf_destroy(None) == 0 and lib.mmc_sf_init(None) == -1
