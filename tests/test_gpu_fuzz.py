@@ -17,3 +17,14 @@ def test_random_small_configurations(seed):
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "misses 0" in res.stdout
+
+
+def test_random_medium_configurations():
+    """tools/fuzz_medium.py: tens to hundreds of tiles per frame, 2 to 6 frames, outlier vectors, against the
+    C restatement at 12 iterations, relative L2 <= 2e-5."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_medium.py"), "40", "21"],
+                         capture_output=True, text=True, timeout=600)
+    if "C oracle not built" in res.stdout + res.stderr:
+        pytest.skip("C oracle not built")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "misses 0" in res.stdout
