@@ -14,6 +14,12 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
+    import spawn
+    spawn.start()          # the helper that starts child programs, before this process touches the GPU (tests/spawn.py)
+    _sessionstart_crashtrace(session)
+
+
+def _sessionstart_crashtrace(session):
     """Native call stacks for crashes inside shared libraries (see tests/capi_client/crashtrace.c);
     installed after pytest's faulthandler, which still prints the Python stack afterwards."""
     import ctypes

@@ -1,7 +1,7 @@
 """The C ABI driven from a plain C program (tests/capi_client/capi_client.c, built with gcc against
 include/mmc_hip.h): the same problem as the ctypes path, checked against the oracle."""
 import os
-import subprocess
+import spawn
 
 import numpy as np
 import pytest
@@ -18,7 +18,7 @@ CLIENT = os.path.join(CLIENT_DIR, "capi_client")
 
 def _client():
     if not os.path.exists(CLIENT):
-        subprocess.run(["make", "-C", CLIENT_DIR], check=True)
+        assert spawn.run(["make", "-C", CLIENT_DIR]).returncode == 0
     return CLIENT
 
 
@@ -42,7 +42,7 @@ def test_c_program_reproduces_the_oracle(tmp_path, kappa, direction):
         fh.write(np.array([P.alpha, kappa], dtype=np.float32).tobytes())
         fh.write(f32(f)); fh.write(f32(k)); fh.write(f32(v)); fh.write(f32(P.u_up)); fh.write(f32(P.u_up))
         fh.write(np.asarray(occ, dtype=np.uint8).ravel(order="F").tobytes())
-    res = subprocess.run([_client(), str(inp), str(out)], capture_output=True, text=True, timeout=120)
+    res = spawn.run([_client(), str(inp), str(out)], timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     raw = open(out, "rb").read()
     M = Ny * Nx * nc
@@ -59,5 +59,5 @@ def test_c_program_reports_library_errors(tmp_path):
         fh.write(np.array([4, 4, 2, 4, 6, 6, 5, 1, 0], dtype=np.int32).tobytes())
         fh.write(np.array([0.01, 0.25], dtype=np.float32).tobytes())
         fh.write(np.zeros(4 * 4 * 2 + 36 + 16 * 16 * 2 + 2 * 16 * 16 * 2, dtype=np.float32).tobytes())
-    res = subprocess.run([_client(), str(inp), str(out)], capture_output=True, text=True, timeout=120)
+    res = spawn.run([_client(), str(inp), str(out)], timeout=120)
     assert res.returncode == 2 and "even dimensions" in res.stderr

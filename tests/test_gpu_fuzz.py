@@ -2,10 +2,11 @@
 frames from 1 x 1 low-resolution pixels to several tiles, zoom factors 1..5, 1..4 frames, every model
 and flow direction, masks, blur kernels 1x1..7x7 or none; 25 iterations, relative L2 <= 1e-4."""
 import os
-import subprocess
 import sys
 
 import pytest
+
+import spawn
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,8 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_small_configurations(seed):
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shapes.py"), "150", str(seed)],
-                         capture_output=True, text=True, timeout=600)
+    res = spawn.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shapes.py"), "150", str(seed)], timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "misses 0" in res.stdout
 
@@ -22,8 +22,7 @@ def test_random_small_configurations(seed):
 def test_random_medium_configurations():
     """tools/fuzz_medium.py: tens to hundreds of tiles per frame, 2 to 6 frames, outlier vectors, against the
     C restatement at 12 iterations, relative L2 <= 2e-5."""
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_medium.py"), "40", "21"],
-                         capture_output=True, text=True, timeout=600)
+    res = spawn.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_medium.py"), "40", "21"], timeout=600)
     if "C oracle not built" in res.stdout + res.stderr:
         pytest.skip("C oracle not built")
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
@@ -38,7 +37,6 @@ def test_random_cuts_into_frame_blocks():
     # host pointer (about 2 runs of 600 cases in 5); the same cycles are clean on the system runtime and from a C++
     # driver on either runtime, also under the host AddressSanitizer (tools/asan_group_stress.cpp).
     env = dict(os.environ, FUZZ_SYSTEM_HIP="1")
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_group.py"), "40", "31"],
-                         capture_output=True, text=True, timeout=600, env=env)
+    res = spawn.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_group.py"), "40", "31"], timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "misses 0" in res.stdout
