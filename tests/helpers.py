@@ -61,3 +61,16 @@ def make_sf_case(seed, ny, nx, nf, factor=4, flow="smooth", flow_scale=1.5, with
             v[:, :, i, comp] = smooth_field(rng, (Ny, Nx), flow_scale) if flow == "smooth" else rng.normal(0.0, flow_scale, (Ny, Nx))
     occ = (rng.random((Ny, Nx, nf)) < 0.1).astype(np.uint8) if with_occ else None
     return f, v.astype(np.float32).astype(np.float64), occ
+
+
+def spawn_ranks(module, function, args, world, timeout=280):
+    """torch.multiprocessing.spawn(module.function, args, nprocs=world) from a fresh process (tests/mp_launch.py,
+    started through tests/spawn.py): the ranks are not forked from the test process."""
+    import json
+    import os
+    import sys
+    import spawn
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = spawn.run([sys.executable, os.path.join(here, "mp_launch.py"), module, function, str(world), json.dumps(list(args))],
+                  timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:] + r.stderr[-3000:])

@@ -154,10 +154,10 @@ def _rank(rank, world, port, ny, nx, L, iters, out_dir):
 
 def test_config4_two_ranks_at_1080p(tmp_path):
     _need_c_oracle()
-    import torch.multiprocessing as mp
+    from helpers import spawn_ranks
     ny, nx, L, world, iters = 270, 480, 3, 2, 10
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    mp.spawn(_rank, args=(world, port, ny, nx, L, iters, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks("test_gpu_configs", "_rank", (world, port, ny, nx, L, iters, str(tmp_path)), world)
     f, v, u_up = _synthetic(ny, nx, L * world)
     parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
     h = float(parts[0]["h"])

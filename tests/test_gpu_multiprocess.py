@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import mmc_oracle as orc
-from helpers import make_case, rel_l2
+from helpers import make_case, rel_l2, spawn_ranks
 
 pytestmark = pytest.mark.gpu
 KBLUR = orc.fspecial_gaussian(7, np.sqrt(0.6))
@@ -76,10 +76,9 @@ def test_ranks_on_their_own_gpus_over_rccl(tmp_path, world, nc, kappa, direction
 
 
 def _run_and_check(tmp_path, world, nc, kappa, direction, backend):
-    import torch.multiprocessing as mp
     iters = 30
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    mp.spawn(_worker, args=(world, port, nc, kappa, direction, iters, str(tmp_path), backend), nprocs=world, join=True)
+    spawn_ranks("test_gpu_multiprocess", "_worker", (world, port, nc, kappa, direction, iters, str(tmp_path), backend), world)
     f, v, occ = make_case(41, 8, 10, nc, flow="smooth", flow_scale=2.0, with_occ=True)
     P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
     x, _, chg = orc.pdhg(P, iters)
