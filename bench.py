@@ -20,7 +20,6 @@ import argparse
 import json
 import os
 import socket
-import subprocess
 import sys
 import time
 
@@ -37,7 +36,7 @@ BYTES_PRIMAL = {"ic": 14.0625 * 4, "single": 8.0625 * 4}
 BYTES_DUAL = {"ic": 16.1875 * 4, "single": 9.1875 * 4}
 BYTES_ITER = {"ic": 121.0, "single": 69.0}
 HBM_PEAK = 8.0e12
-PMC_SUMMARIES = ("r2_pmc_hbm_bytes.json", "r1_pmc_hbm_bytes.json")
+PMC_SUMMARIES = ("r3_pmc_hbm_bytes.json", "r2_pmc_hbm_bytes.json", "r1_pmc_hbm_bytes.json")
 
 
 def log(msg):
@@ -88,33 +87,57 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    import subprocess       # the only child process this program starts, and it starts it before any GPU call
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(args, budget_s):
+def host_topology():
+    """Sockets and cores per socket from /proc/cpuinfo (read in-process: no child program is started
+    once the GPU runtime is live)."""
+    try:
+        phys, cores = set(), {}
+        cur = None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("physical id"):
+                    cur = int(ln.split(":")[1])
+                    phys.add(cur)
+                elif ln.startswith("cpu cores") and cur is not None:
+                    cores[cur] = int(ln.split(":")[1])
+        if phys and cores:
+            return {"cores_per_socket": max(cores.values()), "sockets": len(phys)}
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def c_oracle_ready():
+    """Locate (or build, with make) the C restatement.  Called before the first GPU call: building
+    starts a child process."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import mmc_oracle_c as oc
+        return oc.available()
+    except Exception:
+        return False
+
+
+def cpu_baseline(args, budget_s, have_c, keep=None):
     """The oracle's PDHG iteration timed on the host cores with the C/OpenMP restatement: the whole
     single-GPU workload for 50 iterations with stored sparse rows for W' and D*B (the flexBox-style
     path), a 4-frame sample in the mode that stores no operator, and the reference's own
     quick-start size (600x600x3) for its 800 iterations; with a budget under 10 s only the 4-frame
-    samples; if the C library cannot be built, a small crop with the scipy.sparse restatement."""
+    samples; if the C library is not there, a small crop with the scipy.sparse restatement.
+    keep: a dict that receives the inputs, the start point and the iterate of the whole-workload run
+    (for the parity check of the HIP path against this very run).  Starts no child process."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from superresolution_amd import synthetic
-    try:
-        import mmc_oracle_c as oc
-        have_c = oc.available()
-    except Exception:
-        have_c = False
     k = synthetic.gaussian_kernel()
     host_cpus = os.cpu_count()
     if have_c:
+        import mmc_oracle_c as oc
         ny, nx = args.lr
-        lscpu = None
-        try:
-            txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
-            cores = [ln.split(":")[1].strip() for ln in txt.splitlines() if ln.startswith(("Core(s) per socket", "Socket(s)"))]
-            lscpu = {"cores_per_socket": int(cores[0]), "sockets": int(cores[1])} if len(cores) == 2 else None
-        except Exception:
-            pass
+        lscpu = host_topology()
         stored = "C/OpenMP restatement with the warp adjoint and D*B stored as sparse rows, the way init_u_flexBox hands " \
                  "them to flexBox (oracle/mmc_oracle_c.c); loop time only, operator set-up excluded"
         full = budget_s >= 10.0 and args.frames_per_gpu >= 8
@@ -122,7 +145,10 @@ def cpu_baseline(args, budget_s):
             # the whole single-GPU workload for 50 iterations (the loop takes about 10 s on 16 threads)
             nc, iters = args.frames_per_gpu, 50
             blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
-            res = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, iters=iters)
+            res = oc.time_solve(blk["f"], blk["v"], k, kappa=args.kappa, iters=iters, return_state=keep is not None)
+            if keep is not None:
+                keep.update(f=blk["f"], v=blk["v"], iters=iters, u_up=res.pop("u_up"), u=res.pop("u"), w=res.pop("w"),
+                            h=res.pop("h"), primal_energy=res.pop("primal_energy"), gap=res.pop("gap"))
             sample = "the whole workload (%dx%dx%d HR) for %d iterations; %s" % (4 * ny, 4 * nx, nc, iters, stored)
         else:
             nc = 4
@@ -162,6 +188,27 @@ def cpu_baseline(args, budget_s):
                       % (4 * ny, 4 * nx, nc, iters)}
 
 
+def parity_check(s, keep, model):
+    """Re-runs the solver `s` on the CPU leg's inputs and compares the iterates (float32 both)."""
+    s.set_lowres(keep["f"])
+    s.set_flow(keep["v"])
+    s.set_state(keep["u_up"], keep["u_up"])
+    s.init()
+    st = s.solve(keep["iters"], 0.0, 0)
+    u, w = s.get_state()
+    e = s.diagnostics()
+    du = u.astype(np.float64) - keep["u"]
+    res = {"iters": int(st["iterations"]), "frames": int(u.shape[2]), "hr": [int(u.shape[0]), int(u.shape[1])],
+           "rel_l2_u": float(np.linalg.norm(du) / np.linalg.norm(keep["u"])), "max_abs_u": float(np.abs(du).max()),
+           "h_hip": s.h, "h_cpu": float(keep["h"]),
+           "primal_energy_hip": e["primal_energy"], "primal_energy_cpu": float(keep["primal_energy"]),
+           "gap_hip": e["gap"], "gap_cpu": float(keep["gap"]), "tolerance": "rel_l2_u <= 1e-4 (float32, same iteration count)"}
+    if w is not None and keep["w"] is not None:
+        res["max_abs_w"] = float(np.abs(w.astype(np.float64) - keep["w"]).max())
+    res["ok"] = bool(res["rel_l2_u"] <= 1e-4)
+    return res
+
+
 def measured_traffic(kernel, model, L, Ny, Nx):
     """HBM bytes per launch of `kernel` from the committed hardware-counter summary
     (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes over this same workload;
@@ -191,6 +238,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    # whatever may start a child process (make for the C restatement) happens before the GPU runtime is loaded
+    have_c = c_oracle_ready() if (world == 1 and not args.no_cpu_baseline) else False
 
     import torch
     from superresolution_amd import synthetic
@@ -254,6 +304,8 @@ def main():
     log("rank %d: mmc_init" % rank)
     s.init()
 
+    from superresolution_amd import _capi
+    hip_built, hip_runtime = _capi.hip_versions()
     M_local = Ny * Nx * L
     M_total = Ny * Nx * nc
     prof = None
@@ -342,7 +394,8 @@ def main():
                                       args.kappa, args.direction, args.flow),
                        "frames_total": nc, "hr_pixels_total": M_total, "parallelism": "frame-block x%d" % world,
                        "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
-                       "plane_skew_bytes": s.plane_skew},
+                       "plane_skew_bytes": s.plane_skew,
+                       "hip_built_against": hip_built, "hip_runtime": hip_runtime},
             "wall_s_per_sr_frame_at_7500_iters": wall / args.steps * 7500 / nc,
             "iteration_roofline": {"bytes_per_px_iter": BYTES_ITER[model],
                                    "achieved_GBps_per_gpu": BYTES_ITER[model] * M_total * args.steps / wall / world / 1e9,
@@ -373,10 +426,19 @@ def main():
                                 "k_dual4_roofline_frac": BYTES_DUAL[model] * M_local / (ms_d * 1e-3) / HBM_PEAK}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline")
+            keep = {}
             try:
-                out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, have_c, keep)
             except Exception as e:      # the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            if "u" in keep and args.direction == "backward":
+                # The HIP path on the inputs and from the start point of the CPU run above, for the same
+                # number of iterations: the iterate at the size that was timed, against the oracle's.
+                log("parity check against the cpu run (%d iterations)" % keep["iters"])
+                try:
+                    out["parity_check"] = parity_check(s, keep, model)
+                except Exception as e:
+                    out["parity_check"] = {"error": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
     s.close()

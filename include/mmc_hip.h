@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMC_ABI_VERSION 2
+#define MMC_ABI_VERSION 3
 
 typedef enum mmc_status {
     MMC_OK = 0,
@@ -79,14 +79,45 @@ typedef struct mmc_params {
     void *stream;              /* hipStream_t to queue on; NULL: the library makes one */
 } mmc_params;
 
-/* Result of a solve / of the last residual check. */
+/* Result of a solve / of the last residual check.
+ * The first group is reduced inside the update sweeps at every check.  The second group (the
+ * "diagnostics") takes two more read-only passes over the block, about the cost of one iteration:
+ * it is filled at a check when diagnostics are on (mmc_set_diagnostics) and is NaN otherwise.
+ *   primal_energy  ||A u - f||_1 + alpha sum_j ||(K1(u - w))_j|| + alpha sum_j ||(K2 w)_j|| at the
+ *                  iterate (the quantity prost prints, MultiframeMotionCoupling.m:357-359); the box
+ *                  on u holds exactly, the equality rows of a pinned first frame are not counted
+ *   dual_energy    -<f,p> - <u0,q1> - <w0,q2> - sum_j max(0, -(K'y)_u,j): the dual objective
+ *                  -F*(y) - G*(-K'y) without the condition (K'y)_w = 0 that the free variable w
+ *                  imposes (the duals lie inside their sets by construction)
+ *   gap            primal_energy - dual_energy
+ *   dual_infeasibility  sum_j |(K'y)_w,j|.  For any bound B >= max|w| at the optimum the optimal
+ *                  energy lies in [dual_energy - B * dual_infeasibility, primal_energy].
+ *   opt_res_primal 2-norm of the smallest element of dG(x) + K'y   (distance from primal optimality)
+ *   opt_res_dual   2-norm of the smallest element of dF*(y) - K x  (distance from dual optimality)
+ *   norm_KTy, norm_Kx   2-norms that scale the relative part of the stopping test
+ * With diagnostics on, a solve with tol > 0 stops when
+ *   opt_res_primal <= tol*sqrt(#primal) + tol*norm_KTy  and  opt_res_dual <= tol*sqrt(#dual) + tol*norm_Kx,
+ * the absolute + relative residual test that the reference asks of prost with all four tolerances
+ * equal to tol_pd (MultiframeMotionCoupling.m:276-280, :357-363).  With diagnostics off it stops when
+ * max(res_primal, res_dual) < tol. */
 typedef struct mmc_stats {
     int32_t iterations;        /* PDHG iterations executed by this call                */
     int32_t converged;         /* 1 if the tolerance test stopped the loop             */
     double res_primal;         /* ||x+ - x||_2 / max(||x+||_2, tiny) at the last check */
     double res_dual;           /* ||y+ - y||_2 / max(||y+||_2, tiny) at the last check */
     double solve_seconds;      /* host wall time of the call, device-synchronised      */
+    double primal_energy, dual_energy, gap, dual_infeasibility;
+    double opt_res_primal, opt_res_dual, norm_KTy, norm_Kx;
 } mmc_stats;
+
+/* Raw sums behind the diagnostics of mmc_stats, for adding up over frame blocks:
+ * [0] regulariser energy  [1] data energy  [2] |K x|^2  [3] dual optimality residual^2
+ * [4] sum max(0,-(K'y)_u) [5] sum |(K'y)_w| [6] |K'y|^2 [7] primal optimality residual^2
+ * [8] <f,p> + <u0,q1> + <w0,q2> */
+#define MMC_NUM_DIAG 9
+/* When the diagnostics are evaluated: never, at the checks of a solve that has a tolerance or a
+ * progress callback (the default), or at every check. */
+typedef enum mmc_diagnostics { MMC_DIAG_OFF = 0, MMC_DIAG_AUTO = 1, MMC_DIAG_ALWAYS = 2 } mmc_diagnostics;
 
 /* Raw sums behind mmc_stats, for all-reducing over frame blocks:
  * [0]=sum (x+ - x)^2  [1]=sum (x+)^2  [2]=sum (y+ - y)^2  [3]=sum (y+)^2 */
@@ -116,6 +147,13 @@ typedef struct mmc_halo {
 typedef struct mmc_handle mmc_handle;
 
 int mmc_abi_version(void);
+
+/* HIP release the library was compiled against and the HIP runtime it runs on in this process,
+ * both encoded as major*10000000 + minor*100000 + patch (HIP_VERSION).  They differ when the
+ * host program brings its own copy of the runtime under the same SONAME (PyTorch-ROCm does);
+ * the pair belongs in every bug report.  Either pointer may be NULL.  No counterpart in the
+ * reference (prost.list_gpus, MultiframeMotionCoupling.m:255, is its only runtime probe). */
+int mmc_hip_versions(int *built_against, int *runtime);
 
 /* Message of the last failure on `h`; with h == NULL the last mmc_create failure
  * of the calling thread. */
@@ -230,7 +268,7 @@ int mmc_h_partials_static(const float *d_u, const float *d_v, int Ny, int Nx, in
 /* The solve: prost.solve / flexBox.runAlgorithm, MultiframeMotionCoupling.m:981,
  * :989.  Runs at most max_iters PDHG iterations; every check_every iterations
  * (and after the last) the residuals are reduced, the callback runs, and the
- * loop stops if tol > 0 and max(res_primal,res_dual) < tol.  Only for a block
+ * loop stops if tol > 0 and the tolerance test passes (see mmc_stats).  Only for a block
  * without neighbours; blocks of a sharded sequence are driven sweep by sweep. */
 int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_every,
               mmc_stats *stats, mmc_progress_cb cb, void *user);
@@ -245,6 +283,23 @@ int mmc_sums_reset(mmc_handle *h);
 int mmc_sums_read(mmc_handle *h, double out[MMC_NUM_SUMS]);   /* synchronises */
 int mmc_halo_info(mmc_handle *h, mmc_halo *out);
 int mmc_sync(mmc_handle *h);
+
+/* Diagnostics (second group of mmc_stats) for a block driven sweep by sweep.
+ * mmc_diag_partials evaluates the block's share of the sums at its current iterate and duals
+ * (read-only; synchronises).  A block with a previous neighbour needs that neighbour's temporal
+ * duals in its ghost slot (they are, after the exchange that follows a dual sweep); a block with a
+ * next neighbour needs the neighbour's first frame of u and w -- the iterate, not xbar -- in the
+ * ghost slot that mmc_state_halo_info names (send_prev -> the previous block's recv_next; the
+ * other entries are NULL): exchange it before the call.  mmc_problem_size gives the block's number
+ * of primal and dual unknowns.  mmc_stats_from_diag turns sums added up over all blocks into the
+ * diagnostics fields of *st (the other fields are left alone) and returns 1 if they pass the
+ * residual test for `tol` (0 when tol <= 0).  No counterpart in the reference: prost computes its
+ * residuals and progress output inside prost.solve (MultiframeMotionCoupling.m:357-363, :981). */
+int mmc_set_diagnostics(mmc_handle *h, int mode);
+int mmc_diag_partials(mmc_handle *h, double out[MMC_NUM_DIAG]);
+int mmc_state_halo_info(mmc_handle *h, mmc_halo *out);
+int mmc_problem_size(const mmc_handle *h, double *n_primal, double *n_dual);
+int mmc_stats_from_diag(const double diag[MMC_NUM_DIAG], double n_primal, double n_dual, float tol, mmc_stats *st);
 
 /* Per-kernel timing of mmc_solve with HIP events recorded on the library's
  * stream around every launch (the reference only has tic/toc around run,
@@ -266,7 +321,8 @@ int mmc_get_sweep_profile(mmc_handle *h, double total_ms[2], int calls[2]);
 int mmc_get_state(mmc_handle *h, float *u, float *w);
 
 /* Primal objective of the current iterate restricted to this block:
- * ||A u - f||_1 + regulariser, for logging (the quantity prost prints). */
+ * ||A u - f||_1 + regulariser, for logging (the quantity prost prints).  Only for a block without
+ * a next neighbour (use mmc_diag_partials otherwise). */
 int mmc_energy(mmc_handle *h, double *value);
 
 /* ---- One sequence on several GPUs from ONE host thread ------------------------
@@ -313,6 +369,8 @@ int mmc_group_set_h(mmc_group *g, float value);
 int mmc_group_solve(mmc_group *g, int max_iters, float tol, int check_every,
                     mmc_stats *stats, mmc_progress_cb cb, void *user);
 int mmc_group_get_state(mmc_group *g, float *u, float *w);
+/* mmc_set_diagnostics for every block of the group */
+int mmc_group_set_diagnostics(mmc_group *g, int mode);
 
 /* ---- Test hooks: the operators of the sweeps without the prox maps. ---------
  * K x for x = (u, w): out_p is n*L, out_g1/out_g2 are component-major
@@ -345,7 +403,7 @@ size_t mmc_debug_plane_skew(const mmc_handle *h);
  * classical methods/singleframeMotionSR_mitzel_prost.m, ..._mitzel_prost_fast.m and
  * ..._unger_prost.m assemble, after their flow estimation (which stays on the reference path),
  * one problem for prost.solve (..._mitzel_prost.m:82-172):
- *     min_u  sum_i H_delta(D B W_i u - f_i) + alpha TV(u)
+ *     min_u  sum_i H_delta(D B W_i u - f_i) + alpha sum_j H_delta(|grad u|_j)
  * u: the central high-resolution frame (N = Ny*Nx); f_i: low-resolution frame i; W_i: bilinear
  * warp with the flow from the central frame to frame i (:64-70); D the box sampler of :75-77
  * (= 'average'), B the blur of :78-79; H_delta the Huber function, delta = 0 the absolute value
@@ -360,7 +418,8 @@ typedef struct mmc_sf_params {
     int32_t factor;            /* zoom factor */
     int32_t num_frames;        /* low-resolution frames; the central one is ceil(num_frames/2), 1-based (:21) */
     float alpha;               /* weight of TV: ||q_j|| <= alpha (:163) */
-    float huber_eps;           /* delta >= 0 */
+    float huber_eps;           /* delta >= 0: Huber parameter of the data terms (..._unger_prost.m:148-161) and of the
+                                  regulariser (dual term (delta/alpha)/2 ||q_j||^2, ..._unger_prost.m:163); 0 for Mitzel */
     int32_t sampling;          /* MMC_SAMPLING_AVERAGE (factor 4) or MMC_SAMPLING_STRIDE */
     int32_t device;
     void *stream;              /* hipStream_t to queue on; NULL: the library makes one */

@@ -79,7 +79,9 @@ mxArray *to_double(const std::vector<float> &v, mwSize Ny, mwSize Nx, mwSize nc)
 }
 
 int progress(int it, const mmc_stats *st, void *) {
-    mexPrintf("  it %6d  res_primal %.3e  res_dual %.3e  (%.2f s)\n", it, st->res_primal, st->res_dual, st->solve_seconds);
+    // the progress lines prost prints 5 times per solve (MultiframeMotionCoupling.m:357-359)
+    mexPrintf("  it %6d  energy %.6e  gap %.3e  res_primal %.3e  res_dual %.3e  (%.2f s)\n", it, st->primal_energy, st->gap,
+              st->opt_res_primal, st->opt_res_dual, st->solve_seconds);
     return 0;
 }
 
@@ -244,8 +246,15 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         plhs[0] = to_double(u, Ny, Nx, nc);
         if (nlhs > 1) plhs[1] = has_w ? to_double(w, Ny, Nx, nc) : mxCreateDoubleMatrix(0, 0, mxREAL);
         if (nlhs > 2) {
-            const char *names[] = {"iterations", "converged", "res_primal", "res_dual", "seconds"};
-            plhs[2] = mxCreateStructMatrix(1, 1, 5, names);
+            const char *names[] = {"iterations", "converged", "res_primal", "res_dual", "seconds", "primal_energy", "dual_energy",
+                                   "gap", "dual_infeasibility", "opt_res_primal", "opt_res_dual"};
+            plhs[2] = mxCreateStructMatrix(1, 1, 11, names);
+            mxSetField(plhs[2], 0, "primal_energy", mxCreateDoubleScalar(st.primal_energy));
+            mxSetField(plhs[2], 0, "dual_energy", mxCreateDoubleScalar(st.dual_energy));
+            mxSetField(plhs[2], 0, "gap", mxCreateDoubleScalar(st.gap));
+            mxSetField(plhs[2], 0, "dual_infeasibility", mxCreateDoubleScalar(st.dual_infeasibility));
+            mxSetField(plhs[2], 0, "opt_res_primal", mxCreateDoubleScalar(st.opt_res_primal));
+            mxSetField(plhs[2], 0, "opt_res_dual", mxCreateDoubleScalar(st.opt_res_dual));
             mxSetField(plhs[2], 0, "iterations", mxCreateDoubleScalar(st.iterations));
             mxSetField(plhs[2], 0, "converged", mxCreateDoubleScalar(st.converged));
             mxSetField(plhs[2], 0, "res_primal", mxCreateDoubleScalar(st.res_primal));

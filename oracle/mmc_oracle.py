@@ -652,6 +652,131 @@ def primal_energy(P, x):
     return float(e)
 
 
+# --------------------------------------------------------------------------
+# Optimality certificates: dual objective, primal-dual gap, residuals.
+# These depend on the MODEL only (K, f, the radii), not on any step-size DECISION.
+# --------------------------------------------------------------------------
+
+
+def dual_terms(P, y):
+    """Pieces of the dual objective  D(y) = -F*(y) - G*(-K'y)  for a dual point inside its
+    constraint sets (what every prox_Fstar returns):
+      lin        <f,p> (+ <u0,q1> + <w0,q2>): the linear parts of F*  (:496, :563-564)
+      box_u      G*(-K'y) on u, G = indicator of [0,1] (:495):  sum_j max(0, -(K'y)_u,j)
+      infeas_w   sum_j |(K'y)_w,j|: w is free (G = 0), so D is finite only where this is 0
+    """
+    KTy = P.KT @ y
+    lin = 0.0
+    off = 0
+    for name, size, kind, par in P.dual_blocks:
+        yy = y[off:off + size]
+        if kind == 'box_lin':
+            lin += float(np.dot(par[1], yy))
+        elif kind == 'lin':
+            lin += float(np.dot(par[0], yy))
+        off += size
+    box_u = float(np.maximum(-KTy[:P.M], 0.0).sum())
+    infeas_w = float(np.abs(KTy[P.M:]).sum()) if len(P.primal) == 2 else 0.0
+    return {'lin': lin, 'box_u': box_u, 'infeas_w': infeas_w}
+
+
+def dual_energy(P, y, w_bound=0.0):
+    """D(y) with w confined to [-w_bound, w_bound] (G*_w(z) = w_bound * |z|_1).  w_bound = 0 is
+    the relaxed value that ignores the constraint K_w'y = 0; any w_bound >= max|w*| gives a valid
+    lower bound of the optimal primal energy."""
+    t = dual_terms(P, y)
+    return -t['lin'] - t['box_u'] - w_bound * t['infeas_w']
+
+
+def primal_dual_gap(P, x, y, w_bound=0.0):
+    """primal_energy(x) - dual_energy(y, w_bound) for x inside the box and y inside its sets."""
+    return primal_energy(P, x) - dual_energy(P, y, w_bound)
+
+
+def optimality_residuals(P, x, y):
+    """Distance of (x, y) from the optimality conditions, independent of step sizes:
+      primal: min-norm element of  dG(x) + K'y   (u: projected onto the normal cone of the box)
+      dual  : min-norm element of  dF*(y) - Kx   (per block, projected onto the normal cone of the
+              constraint set of y; the 'lin' blocks have dF* = {x0})
+    Returns (r_primal, r_dual, |K'y|, |Kx|) as 2-norms; a solver in the spirit of prost's
+    abs+rel test (MultiframeMotionCoupling.m:357-363) stops when
+      r_primal <= tol*sqrt(len x) + tol*|K'y|  and  r_dual <= tol*sqrt(len y) + tol*|Kx|."""
+    KTy = P.KT @ y
+    Kx = P.K @ x
+    M = P.M
+    gu = KTy[:M].copy()            # need -gu in N_[0,1](u)
+    u = x[:M]
+    at0, at1 = u <= 0.0, u >= 1.0
+    gu[at0] = np.minimum(gu[at0], 0.0)      # at u = 0 the cone is (-inf, 0]: -gu <= 0 is fine, gu < 0 violates
+    gu[at1] = np.maximum(gu[at1], 0.0)
+    rp2 = float((gu * gu).sum() + (KTy[M:] ** 2).sum())
+    rd2 = 0.0
+    off = 0
+    for name, size, kind, par in P.dual_blocks:
+        yy = y[off:off + size]
+        z = Kx[off:off + size]
+        if kind == 'box_lin' or kind == 'box':
+            bound = par[0]
+            d = z - (par[1] if kind == 'box_lin' else 0.0)          # need d in N_[-b,b](y)
+            r = d.copy()
+            up, lo = yy >= bound, yy <= -bound
+            r[up] = np.minimum(d[up], 0.0)
+            r[lo] = np.maximum(d[lo], 0.0)
+            rd2 += float((r * r).sum())
+        elif kind == 'lin':
+            d = z - par[0]
+            rd2 += float((d * d).sum())
+        elif kind == 'ball':
+            rad, gdim, glen = par
+            g = yy.reshape(gdim, glen)
+            d = z.reshape(gdim, glen)
+            nrm = np.sqrt((g * g).sum(axis=0))
+            on = nrm * nrm >= rad * rad * (1.0 - 1e-5)        # same threshold as the float32 implementations
+            # on the sphere the cone is {lambda g, lambda >= 0}: remove the non-negative radial part
+            lam = np.where(on, np.maximum((d * g).sum(axis=0), 0.0) / np.where(nrm > 0, nrm * nrm, 1.0), 0.0)
+            r = d - lam[None, :] * g
+            rd2 += float((r * r).sum())
+        off += size
+    return np.sqrt(rp2), np.sqrt(rd2), float(np.linalg.norm(KTy)), float(np.linalg.norm(Kx))
+
+
+def operator_norm(P, iters=200, seed=0):
+    """|K|_2 by power iteration on K'K."""
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=P.K.shape[1])
+    x /= np.linalg.norm(x)
+    s = 0.0
+    for _ in range(iters):
+        z = P.KT @ (P.K @ x)
+        s = np.linalg.norm(z)
+        x = z / s
+    return float(np.sqrt(s))
+
+
+def pdhg_scalar(P, iters, x=None, y=None, ratio=1.0, norm=None, callback=None, every=0):
+    """Plain Chambolle-Pock PDHG with ONE scalar step pair, tau*sigma*|K|^2 = 0.98^2 and
+    tau/sigma = ratio, dual step first:
+        y+ = prox_{sigma F*}(y + sigma K xb);  x+ = prox_G(x - tau K'y+);  xb = 2x+ - x.
+    It shares neither the diagonal preconditioning nor the update order of pdhg() and of the
+    HIP sweeps; it exists to reach the optimum of the same model by another route."""
+    L = operator_norm(P) if norm is None else norm
+    tau = 0.98 / L * np.sqrt(ratio)
+    sigma = 0.98 / L / np.sqrt(ratio)
+    x = (P.x0 if x is None else x).astype(np.float64)
+    y = (P.y0 if y is None else y).astype(np.float64)
+    xb = x.copy()
+    S = np.full(P.K.shape[0], sigma)
+    for it in range(iters):
+        y = prox_Fstar(P, y + sigma * (P.K @ xb), S)
+        xn = prox_G(P, x - tau * (P.KT @ y))
+        xb = 2.0 * xn - x
+        x = xn
+        if callback is not None and every and (it + 1) % every == 0:
+            if callback(it + 1, x, y):
+                break
+    return x, y
+
+
 def split_primal(P, x):
     Ny, Nx, nc = P.dims[:3]
     u = x[:P.M].reshape((Ny, Nx, nc), order='F')

@@ -185,6 +185,20 @@ static taps make_taps(int Ny, int Nx, int r, int c, float vx, float vy) {
     return t;
 }
 
+/* squared distance of d from the normal cone of the ball of radius R at g ({0} inside, {lambda g} on the sphere) */
+static double ball_res2(float dt, float dx, float dy, float gt, float gx, float gy, float R) {
+    const float n2 = gt * gt + gx * gx + gy * gy;
+    float lam = 0.0f, rt, rx, ry;
+    if (n2 > 0.0f && n2 >= R * R * (1.0f - 1e-5f)) { lam = (dt * gt + dx * gx + dy * gy) / n2; if (lam < 0.0f) lam = 0.0f; }
+    rt = dt - lam * gt; rx = dx - lam * gx; ry = dy - lam * gy;
+    return (double)rt * rt + (double)rx * rx + (double)ry * ry;
+}
+/* ... of the interval [-b, b] at y */
+static double box_res2(float d, float y, float b) {
+    const float r = y >= b ? (d < 0.0f ? d : 0.0f) : (y <= -b ? (d > 0.0f ? d : 0.0f) : d);
+    return (double)r * r;
+}
+
 static int pair_is_IF(int dir, int q) { return dir == 1 ? 1 : (dir == 0 ? 0 : ((q & 1) == 0)); }
 
 /* taps of pixel j of pair q: stored (tp != NULL) or recomputed from the flow */
@@ -199,7 +213,12 @@ static taps get_taps(const taps *tp, const float *v, const unsigned char *occ, i
 
 /* Returns 0 on success.  u, w: start point in, result out (w may be NULL for the models without w).
  * out[0..3] = sum(x+-x)^2, sum(x+)^2, sum(y+-y)^2, sum(y+)^2 of the last iteration, out[4] = h,
- * out[5] = seconds spent in the iteration loop, out[6] = threads used. */
+ * out[5] = seconds spent in the iteration loop, out[6] = threads used.
+ * out[8..16]: the model's optimality measures at the final (x, y), evaluated in one extra read-only pass
+ * (they depend on K, f and the radii only, not on the step sizes):
+ *   [8] regulariser energy  [9] data energy ||Au-f||_1  [10] |K x|^2  [11] dist(K x, dF*(y))^2
+ *   [12] sum max(0,-(K'y)_u)  [13] sum |(K'y)_w|  [14] |K'y|^2  [15] dist(-K'y, dG(x))^2  [16] <f,p>
+ * primal energy = [8]+[9]; dual objective (without the condition (K'y)_w = 0) = -[16] - [12]. */
 int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const unsigned char *occ,
                const float *k, float *u, float *w, int iters, int nthreads, double *out) {
     const int f = P->factor, ny = P->ny, nx = P->nx, nc = P->nc, Ny = ny * f, Nx = nx * f;
@@ -212,6 +231,7 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
     taps *tp;
     float *cW, *cA, *sigp, *ub, *wb, *p, *g1, *g2, h, inv_h;
     double s_dx = 0, s_x = 0, s_dy = 0, s_y = 0, t_loop = 0;
+    double d_reg = 0, d_data = 0, d_kx2 = 0, d_rd2 = 0, d_box = 0, d_inf = 0, d_kty2 = 0, d_rp2 = 0, d_lin = 0;
     int q, it;
     long long jj;
     if ((P->sampling == 0 && f != 4) || (P->kh > 0 && ((P->kh & 1) == 0 || (P->kw & 1) == 0))) return -1;
@@ -328,9 +348,15 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
 #ifdef _OPENMP
         double t0 = omp_get_wtime();
 #endif
-        for (it = 0; it < iters; ++it) {
+        for (it = 0; it <= iters; ++it) {
             const int last = it == iters - 1;
+            const int eval = it == iters;       /* extra read-only pass: optimality measures at the final (x, y) */
+            const float *xsrc = eval ? u : ub, *zsrc = (eval && model == 0) ? w : wb;
             double a_dx = 0, a_x = 0, a_dy = 0, a_y = 0;
+            double e_reg = 0, e_data = 0, e_kx2 = 0, e_rd2 = 0, e_box = 0, e_inf = 0, e_kty2 = 0, e_rp2 = 0, e_lin = 0;
+#ifdef _OPENMP
+            if (eval) t_loop = omp_get_wtime() - t0;
+#endif
             if (mf) {
                 /* W' y as a scatter: every unmasked row adds its four taps into the warped frame */
                 memset(wt1, 0, M * sizeof(float));
@@ -355,7 +381,7 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                 }
             }
             /* primal: x+ = prox_G(x - T K'y), xbar = 2x+ - x */
-#pragma omp parallel for reduction(+ : a_dx, a_x) schedule(static)
+#pragma omp parallel for reduction(+ : a_dx, a_x, e_box, e_inf, e_kty2, e_rp2) schedule(static)
             for (jj = 0; jj < (long long)M; ++jj) {
                 const int t = (int)(jj / N), j = (int)(jj % N), r = j % Ny, c = j / Ny;
                 const size_t o = (size_t)t * N;
@@ -398,6 +424,25 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                 KTu = ATp + inv_h * Wt1 + kap * div1;
                 tau_u = 1.0f / (cA[j] + cw + kap * cgrad);
                 uo = u[o + j];
+                if (eval) {
+                    const float ru = uo <= 0.0f ? (KTu < 0.0f ? KTu : 0.0f) : (uo >= 1.0f ? (KTu > 0.0f ? KTu : 0.0f) : KTu);
+                    e_box += KTu < 0.0f ? -(double)KTu : 0.0;
+                    e_kty2 += (double)KTu * KTu;
+                    e_rp2 += (double)ru * ru;
+                    if (model == 0) {
+                        const float *gx = g2 + M + o, *gy = g2 + 2 * M + o;
+                        float KTw;
+                        if (c > 0) div2 += gx[j - Ny];
+                        if (c < Nx - 1) div2 -= gx[j];
+                        if (r > 0) div2 += gy[j - 1];
+                        if (r < Ny - 1) div2 -= gy[j];
+                        KTw = inv_h * Wt2 - kap * div1 + div2;
+                        e_inf += fabs((double)KTw);
+                        e_kty2 += (double)KTw * KTw;
+                        e_rp2 += (double)KTw * KTw;
+                    }
+                    continue;
+                }
                 un = uo - tau_u * KTu;
                 un = un < 0.0f ? 0.0f : (un > 1.0f ? 1.0f : un);          /* G = ind[0,1], :495 */
                 u[o + j] = un;
@@ -420,26 +465,33 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                 }
             }
             /* dual, data term: p <- clamp(p + s (A xbar - f), -1, 1), :496 */
-#pragma omp parallel for reduction(+ : a_dy, a_y) schedule(static)
+#pragma omp parallel for reduction(+ : a_dy, a_y, e_data, e_kx2, e_rd2, e_lin) schedule(static)
             for (jj = 0; jj < (long long)n * nc; ++jj) {
                 const int t = (int)(jj / n), i = (int)(jj % n);
-                const float *x = ub + (size_t)t * N;
+                const float *x = xsrc + (size_t)t * N;
                 float acc = 0.0f, po = p[jj], pn;
                 int e;
                 if (mf) acc = apply_A_mf(&ck, f, Ny, Nx, x, i % ny, i / ny);
                 else for (e = A.ptr[i]; e < A.ptr[i + 1]; ++e) acc += A.val[e] * x[A.idx[e]];
+                if (eval) {
+                    e_data += fabs((double)(acc - f_lr[jj]));
+                    e_kx2 += (double)acc * acc;
+                    e_rd2 += box_res2(acc - f_lr[jj], po, 1.0f);
+                    e_lin += (double)f_lr[jj] * po;
+                    continue;
+                }
                 pn = po + sigp[i] * (acc - f_lr[jj]);
                 pn = pn < -1.0f ? -1.0f : (pn > 1.0f ? 1.0f : pn);
                 p[jj] = pn;
                 if (last) { a_dy += (double)(pn - po) * (pn - po); a_y += (double)pn * pn; }
             }
             /* dual, regulariser: g <- proj(g + S K xbar), :497-498, :513, :532-533 */
-#pragma omp parallel for reduction(+ : a_dy, a_y) schedule(static)
+#pragma omp parallel for reduction(+ : a_dy, a_y, e_reg, e_kx2, e_rd2) schedule(static)
             for (jj = 0; jj < (long long)M; ++jj) {
                 const int t = (int)(jj / N), j = (int)(jj % N), r = j % Ny, c = j / Ny;
                 const size_t o = (size_t)t * N;
                 const int hasx = c < Nx - 1, hasy = r < Ny - 1;
-                const float *x = ub + o, *z = wb + o;
+                const float *x = xsrc + o, *z = zsrc + o;
                 const float uc = x[j], ux = hasx ? x[j + Ny] : uc, uy = hasy ? x[j + 1] : uc;
                 const float wc = z[j], wx = hasx ? z[j + Ny] : wc, wy = hasy ? z[j + 1] : wc;
                 float tu = 0.0f, tw = 0.0f, k1t, k1x, k1y, k2t = 0, k2x = 0, k2y = 0, rs1, rs2 = 0.0f, sg1, sg2;
@@ -452,11 +504,11 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                     if (valid) {
                         const int isIF = pair_is_IF(P->flow_direction, t);
                         const size_t ow = (size_t)(isIF ? t + 1 : t) * N, oi = (size_t)(isIF ? t : t + 1) * N;
-                        tu = tt->w[0] * ub[ow + tt->idx[0]] + tt->w[1] * ub[ow + tt->idx[1]] + tt->w[2] * ub[ow + tt->idx[2]] +
-                             tt->w[3] * ub[ow + tt->idx[3]] - ub[oi + j];
+                        tu = tt->w[0] * xsrc[ow + tt->idx[0]] + tt->w[1] * xsrc[ow + tt->idx[1]] + tt->w[2] * xsrc[ow + tt->idx[2]] +
+                             tt->w[3] * xsrc[ow + tt->idx[3]] - xsrc[oi + j];
                         if (model == 0)
-                            tw = tt->w[0] * wb[ow + tt->idx[0]] + tt->w[1] * wb[ow + tt->idx[1]] +
-                                 tt->w[2] * wb[ow + tt->idx[2]] + tt->w[3] * wb[ow + tt->idx[3]] - wb[oi + j];
+                            tw = tt->w[0] * zsrc[ow + tt->idx[0]] + tt->w[1] * zsrc[ow + tt->idx[1]] +
+                                 tt->w[2] * zsrc[ow + tt->idx[2]] + tt->w[3] * zsrc[ow + tt->idx[3]] - zsrc[oi + j];
                     }
                 }
                 if (model == 0) {
@@ -482,6 +534,21 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                 }
                 sg1 = rs1 > 0.0f ? 1.0f / rs1 : 1.0f;
                 sg2 = rs2 > 0.0f ? 1.0f / rs2 : 1.0f;
+                if (eval) {
+                    e_kx2 += (double)k1t * k1t + (double)k1x * k1x + (double)k1y * k1y + (double)k2t * k2t + (double)k2x * k2x + (double)k2y * k2y;
+                    if (model == 2) {
+                        e_reg += rad1 * fabs((double)k1t) + rad2 * sqrt((double)k1x * k1x + (double)k1y * k1y);
+                        e_rd2 += box_res2(k1t, o1t, rad1) + ball_res2(0.0f, k1x, k1y, 0.0f, o1x, o1y, rad2);
+                    } else {
+                        e_reg += rad1 * sqrt((double)k1t * k1t + (double)k1x * k1x + (double)k1y * k1y);
+                        e_rd2 += ball_res2(k1t, k1x, k1y, o1t, o1x, o1y, rad1);
+                        if (model == 0) {
+                            e_reg += rad2 * sqrt((double)k2t * k2t + (double)k2x * k2x + (double)k2y * k2y);
+                            e_rd2 += ball_res2(k2t, k2x, k2y, g2[o + j], g2[M + o + j], g2[2 * M + o + j], rad2);
+                        }
+                    }
+                    continue;
+                }
                 if (model == 2) {
                     n1t = valid ? o1t + sg1 * k1t : 0.0f;
                     n1t = n1t < -rad1 ? -rad1 : (n1t > rad1 ? rad1 : n1t);
@@ -514,10 +581,11 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
                 }
             }
             if (last) { s_dx = a_dx; s_x = a_x; s_dy = a_dy; s_y = a_y; }
+            if (eval) {
+                d_reg = e_reg; d_data = e_data; d_kx2 = e_kx2; d_rd2 = e_rd2; d_box = e_box; d_inf = e_inf;
+                d_kty2 = e_kty2; d_rp2 = e_rp2; d_lin = e_lin;
+            }
         }
-#ifdef _OPENMP
-        t_loop = omp_get_wtime() - t0;
-#endif
     }
     if (out) {
         out[0] = s_dx; out[1] = s_x; out[2] = s_dy; out[3] = s_y; out[4] = h; out[5] = t_loop;
@@ -526,6 +594,9 @@ int mmco_solve(const mmco_params *P, const float *f_lr, const float *v, const un
 #else
         out[6] = 1;
 #endif
+        out[7] = 0;
+        out[8] = d_reg; out[9] = d_data; out[10] = d_kx2; out[11] = d_rd2; out[12] = d_box; out[13] = d_inf;
+        out[14] = d_kty2; out[15] = d_rp2; out[16] = d_lin;
     }
     if (WT) for (q = 0; q < npairs; ++q) csr_free(&WT[q]);
     free(WT); free(tp); free(cW); free(cA); free(sigp); free(ub); free(wb); free(p); free(g1); free(g2);

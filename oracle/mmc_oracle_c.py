@@ -62,19 +62,27 @@ def solve(f_lr, v, u0, w0, iters, k=None, factor=4, alpha=0.01, kappa=0.25, flow
     u = f32(u0).copy(order="F")
     has_w = not (np.isnan(kappa) or kappa == 1)
     w = f32(w0).copy(order="F") if has_w else None
-    out = (C.c_double * 8)()
+    out = (C.c_double * 24)()
     fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
     ptr = lambda a: None if a is None else a.ctypes.data_as(fp)
     rc = lib.mmco_solve(C.byref(p), ptr(f_lr), ptr(vv), None if oo is None else oo.ctypes.data_as(up), ptr(kk),
                         ptr(u), ptr(w), int(iters), int(threads), out)
     if rc != 0:
         raise RuntimeError("mmco_solve: unsupported parameters")
-    info = {"sums": np.array(out[0:4]), "h": out[4], "loop_seconds": out[5], "threads": int(out[6])}
+    d = np.array(out[8:17])
+    info = {"sums": np.array(out[0:4]), "h": out[4], "loop_seconds": out[5], "threads": int(out[6]),
+            # optimality measures at the returned point (layout of MMC_NUM_DIAG in include/mmc_hip.h)
+            "diag": d, "primal_energy": d[0] + d[1], "dual_energy": -d[8] - d[4], "gap": d[0] + d[1] + d[8] + d[4],
+            "dual_infeasibility": d[5], "opt_res_primal": float(np.sqrt(d[7])), "opt_res_dual": float(np.sqrt(d[3])),
+            "norm_KTy": float(np.sqrt(d[6])), "norm_Kx": float(np.sqrt(d[2]))}
     return u, w, info
 
 
-def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0, max_iters=2000, matrix_free=False, iters=None):
-    """Throughput of the C restatement: iterations sized to roughly fill `budget_s`."""
+def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0, max_iters=2000, matrix_free=False, iters=None,
+               return_state=False):
+    """Throughput of the C restatement: iterations sized to roughly fill `budget_s`.  return_state: also
+    hand back the start point and the iterate reached ("u_up", "u", "w"), for checking another
+    implementation against the very run that was timed."""
     import sys
     sys.path.insert(0, HERE)
     import mmc_oracle as orc
@@ -87,6 +95,9 @@ def time_solve(f_lr, v, k, kappa=0.25, budget_s=15.0, threads=0, max_iters=2000,
         per_it = max(probe["loop_seconds"] / 3, 1e-6)
         iters = int(min(max(budget_s / per_it, 5), max_iters))
     t0 = time.perf_counter()
-    _, _, info = solve(f_lr, v, u_up, u_up, iters, k=k, kappa=kappa, threads=threads, matrix_free=matrix_free)
-    return {"mpx_iter_per_s": M * iters / info["loop_seconds"] / 1e6, "iterations": iters,
-            "threads": info["threads"], "wall_s": time.perf_counter() - t0}
+    u, w, info = solve(f_lr, v, u_up, u_up, iters, k=k, kappa=kappa, threads=threads, matrix_free=matrix_free)
+    out = {"mpx_iter_per_s": M * iters / info["loop_seconds"] / 1e6, "iterations": iters,
+           "threads": info["threads"], "wall_s": time.perf_counter() - t0}
+    if return_state:
+        out.update(u_up=u_up, u=u, w=w, h=info["h"], primal_energy=info["primal_energy"], gap=info["gap"])
+    return out

@@ -8,18 +8,19 @@ What it restates: the problem that classical methods/singleframeMotionSR_mitzel_
 (and ..._mitzel_prost_fast.m, ..._unger_prost.m, which differ in how the flows are estimated and in
 the Huber parameter of the data term) hand to prost.solve:
 
-    min_u  sum_i  H_delta( D B W_i u - f_i )  +  alpha * TV(u)
+    min_u  sum_i  H_delta( D B W_i u - f_i )  +  alpha * sum_j H_delta( |grad u|_j )
 
 one high-resolution frame u (the central one), one data term per low-resolution frame i with the
 warp W_i from the central frame to frame i (flow given; identity for the central frame, :64-70),
 D the 'custom' box sampler {abs(x)<=2)/4, 7} (:75-77, the same rows as interpMethod 'average'),
 B the true convolution with replicate border (RepConvMtx, :78-79), H_delta the Huber function
-(delta = 0: the absolute value; ..._unger_prost.m:148-161 passes huber_eps), TV isotropic.
+(delta = 0: the absolute value; ..._unger_prost.m:148-161, :163 passes huber_eps to the data terms AND to the
+regulariser, which makes it Huber-smoothed TV; the Mitzel files pass 0 to both), TV isotropic.
 
 Saddle-point form as assembled at :97-163:
     primal  u in R^N                                    (:97, no constraint, start value 0)
     duals   p_i in R^n:  ind{|p|<=1} + <f_i,p> + delta/2 |p|^2   (sum_1d('ind_box01',0.5,-0.5,1,f_i,delta), :148-161)
-            q in R^2N:   ind{||q_j||_2 <= alpha}                 (sum_norm2(2,false,'ind_leq0',1/alpha,1,1,0,0), :163)
+            q in R^2N:   ind{||q_j||_2 <= alpha} + (delta/alpha)/2 ||q_j||^2   (sum_norm2(2,false,'ind_leq0',1/alpha,1,1,0,delta/alpha), :163)
     K = [D B W_1; ...; D B W_nf; grad]                            (:128-145)
 
 DECISIONS shared with mmc_oracle.py (the prost backend is absent): warpingOperator = bilinear,
@@ -80,12 +81,14 @@ def build_problem(f_lr, v, factor=4, alpha=0.1, huber_eps=0.0, k=None, sampling=
 
 
 def prox_Fstar(P, y, S):
-    """p <- clamp((p~ - s f) / (1 + s delta), -1, 1);  q_j <- projection onto the alpha-ball."""
+    """p <- clamp((p~ - s f) / (1 + s delta), -1, 1);  q_j <- projection of q~_j / (1 + s delta/alpha) onto
+    the alpha-ball: F*(q) = ind{||q_j|| <= alpha} + (delta/alpha)/2 ||q_j||^2
+    (sum_norm2(2,false,'ind_leq0',1/alpha,1,1,0,huber_eps/alpha), singleframeMotionSR_unger_prost.m:163)."""
     m = P.n * P.nf
     out = np.empty_like(y)
     s = S[:m]
     out[:m] = np.clip((y[:m] - s * P.f.astype(y.dtype)) / (1.0 + s * P.delta), -1.0, 1.0)
-    g = y[m:].reshape(2, P.N)
+    g = (y[m:] / (1.0 + S[m:] * (P.delta / P.alpha))).reshape(2, P.N)
     nrm = np.sqrt((g * g).sum(axis=0))
     scale = np.where(nrm > P.alpha, P.alpha / np.where(nrm > 0, nrm, 1.0), 1.0)
     out[m:] = (g * scale[None, :]).ravel()
@@ -111,7 +114,8 @@ def pdhg(P, iters, x=None, y=None, dtype=np.float64):
 
 
 def primal_energy(P, u):
-    """sum_i H_delta(A W_i u - f_i) + alpha TV(u)."""
+    """sum_i H_delta(A W_i u - f_i) + alpha sum_j H_delta(|grad u|_j): Huber data terms and Huber-smoothed TV
+    (the conjugates of the dual functions of singleframeMotionSR_unger_prost.m:148-163); delta = 0: L1 + TV."""
     z = P.K @ u
     m = P.n * P.nf
     r = np.abs(z[:m] - P.f)
@@ -120,7 +124,12 @@ def primal_energy(P, u):
     else:
         data = r.sum()
     g = z[m:].reshape(2, P.N)
-    return float(data + P.alpha * np.sqrt((g * g).sum(axis=0)).sum())
+    gn = np.sqrt((g * g).sum(axis=0))
+    if P.delta > 0:
+        reg = np.where(gn <= P.delta, gn * gn / (2 * P.delta), gn - P.delta / 2).sum()
+    else:
+        reg = gn.sum()
+    return float(data + P.alpha * reg)
 
 
 def image(P, u):

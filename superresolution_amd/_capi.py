@@ -12,8 +12,10 @@ import numpy as np
 
 from .build import LIB_PATH
 
-MMC_ABI_VERSION = 2
+MMC_ABI_VERSION = 3
 MMC_NUM_SUMS = 4
+MMC_NUM_DIAG = 9
+DIAG_OFF, DIAG_AUTO, DIAG_ALWAYS = 0, 1, 2
 MMC_STATIC_MAX_BLOCKS = 524288
 
 FLOW_FORWARD, FLOW_BACKWARD, FLOW_FORWARD_BACKWARD = 0, 1, 2
@@ -48,7 +50,17 @@ class mmc_sf_params(C.Structure):
 
 class mmc_stats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
-                ("res_primal", C.c_double), ("res_dual", C.c_double), ("solve_seconds", C.c_double)]
+                ("res_primal", C.c_double), ("res_dual", C.c_double), ("solve_seconds", C.c_double),
+                ("primal_energy", C.c_double), ("dual_energy", C.c_double), ("gap", C.c_double),
+                ("dual_infeasibility", C.c_double), ("opt_res_primal", C.c_double), ("opt_res_dual", C.c_double),
+                ("norm_KTy", C.c_double), ("norm_Kx", C.c_double)]
+
+    def as_dict(self):
+        """Every field; the diagnostics group is NaN when it was not evaluated."""
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["converged"] = bool(d["converged"])
+        d["seconds"] = d.pop("solve_seconds")
+        return d
 
 
 class mmc_halo(C.Structure):
@@ -67,6 +79,7 @@ _H = C.c_void_p
 # name -> (restype, argtypes); every symbol include/mmc_hip.h declares
 SIGNATURES = {
     "mmc_abi_version": (C.c_int, []),
+    "mmc_hip_versions": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmc_last_error": (C.c_char_p, [_H]),
     "mmc_create": (C.c_int, [C.POINTER(mmc_params), C.POINTER(_H)]),
     "mmc_destroy": (C.c_int, [_H]),
@@ -92,6 +105,12 @@ SIGNATURES = {
     "mmc_sums_read": (C.c_int, [_H, _dp]),
     "mmc_halo_info": (C.c_int, [_H, C.POINTER(mmc_halo)]),
     "mmc_sync": (C.c_int, [_H]),
+    "mmc_set_diagnostics": (C.c_int, [_H, C.c_int]),
+    "mmc_diag_partials": (C.c_int, [_H, _dp]),
+    "mmc_state_halo_info": (C.c_int, [_H, C.POINTER(mmc_halo)]),
+    "mmc_problem_size": (C.c_int, [_H, _dp, _dp]),
+    "mmc_stats_from_diag": (C.c_int, [_dp, C.c_double, C.c_double, C.c_float, C.POINTER(mmc_stats)]),
+    "mmc_group_set_diagnostics": (C.c_int, [_H, C.c_int]),
     "mmc_set_profiling": (C.c_int, [_H, C.c_int]),
     "mmc_get_profile": (C.c_int, [_H, _dp, C.POINTER(C.c_int)]),
     "mmc_get_sweep_profile": (C.c_int, [_H, _dp, C.POINTER(C.c_int)]),
@@ -161,8 +180,25 @@ def load_library(path=None):
         fn.argtypes = args
     if lib.mmc_abi_version() != MMC_ABI_VERSION:
         raise ImportError("libmmc_hip.so ABI version mismatch")
+    built, runtime = hip_versions(lib)
+    if runtime and built // 100000 != runtime // 100000:
+        import warnings
+        warnings.warn("libmmc_hip.so was built against HIP %s and runs on the HIP %s runtime that was loaded first in "
+                      "this process (PyTorch-ROCm brings its own copy)" % (_fmt_hip(built), _fmt_hip(runtime)), RuntimeWarning)
     _lib = lib
     return lib
+
+
+def _fmt_hip(v):
+    return "%d.%d.%d" % (v // 10000000, (v // 100000) % 100, v % 100000)
+
+
+def hip_versions(lib=None):
+    """(HIP version the library was compiled against, HIP runtime version of this process; 0 if unknown)."""
+    lib = lib or load_library()
+    b, r = C.c_int(0), C.c_int(0)
+    lib.mmc_hip_versions(C.byref(b), C.byref(r))
+    return int(b.value), int(r.value)
 
 
 def as_f32(x):

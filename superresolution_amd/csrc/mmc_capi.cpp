@@ -43,6 +43,7 @@ struct mmc_handle {
     size_t ovf_total = 0;                    // entries in use
     std::string err;
     size_t plane_skew = 0;                   // bytes between the starts of consecutive per-pixel planes modulo their allocation alignment
+    int diagnostics = MMC_DIAG_AUTO;         // when the second group of mmc_stats is evaluated
     bool profiling = false;
     std::vector<hipEvent_t> events;       // 4 per profiled iteration
     double prof_ms[3] = {0, 0, 0};
@@ -107,6 +108,73 @@ static const float PLANE_PROBE_WARM_MS = 40.f, PLANE_PROBE_MARGIN = 0.985f;
 
 extern "C" int mmc_abi_version(void) { return MMC_ABI_VERSION; }
 
+// ---- per-device pool of streams and events (see mmc_internal.h) -------------------------------
+struct DevicePool {
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events[2];      // [0] timing disabled, [1] timing enabled
+};
+static std::mutex g_pool_mutex;
+static std::map<int, DevicePool> g_pool;
+
+hipStream_t mmc_pool_stream_acquire(int device) {
+#ifndef MMC_NO_POOL
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        DevicePool &dp = g_pool[device];
+        if (!dp.streams.empty()) { hipStream_t s = dp.streams.back(); dp.streams.pop_back(); return s; }
+    }
+#endif
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+}
+
+void mmc_pool_stream_release(int device, hipStream_t s) {
+    if (!s) return;
+#ifdef MMC_NO_POOL
+    (void)device;
+    hipStreamDestroy(s);
+#else
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool[device].streams.push_back(s);
+#endif
+}
+
+hipEvent_t mmc_pool_event_acquire(int device, bool timing) {
+#ifndef MMC_NO_POOL
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        std::vector<hipEvent_t> &ev = g_pool[device].events[timing ? 1 : 0];
+        if (!ev.empty()) { hipEvent_t e = ev.back(); ev.pop_back(); return e; }
+    }
+#endif
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+
+void mmc_pool_event_release(int device, bool timing, hipEvent_t e) {
+    if (!e) return;
+#ifdef MMC_NO_POOL
+    (void)device; (void)timing;
+    hipEventDestroy(e);
+#else
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool[device].events[timing ? 1 : 0].push_back(e);
+#endif
+}
+
+// HIP the library was compiled against and the runtime it found loaded in this process (a host
+// program that loads PyTorch-ROCm first runs every HIP library on the copy PyTorch brings along).
+extern "C" int mmc_hip_versions(int *built_against, int *runtime) {
+    if (built_against) *built_against = HIP_VERSION;
+    if (runtime) {
+        *runtime = 0;
+        if (hipRuntimeGetVersion(runtime) != hipSuccess) { (void)hipGetLastError(); return MMC_ERR_HIP; }
+    }
+    return MMC_OK;
+}
+
 extern "C" const char *mmc_last_error(const mmc_handle *h) {
     if (h) return h->err.c_str();
     return g_static_err ? g_static_err : g_create_err.c_str();
@@ -141,9 +209,12 @@ static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, siz
         auto it = g_skew_cache.find(key);
         if (it != g_skew_cache.end() && !getenv("MMC_PROBE_TRACE")) { *skew = it->second; return MMC_OK; }
     }
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0));
-    HIPCHK(h, hipEventCreate(&e1));
+    hipEvent_t e0 = mmc_pool_event_acquire(h->prm.device, true), e1 = mmc_pool_event_acquire(h->prm.device, true);
+    if (!e0 || !e1) {
+        mmc_pool_event_release(h->prm.device, true, e0);
+        mmc_pool_event_release(h->prm.device, true, e1);
+        return fail(h, MMC_ERR_HIP, "plane placement probe: hipEventCreate failed");
+    }
     int rc = MMC_OK;
     const int nfp = std::min(h->L, (int)PLANE_PROBE_FRAMES);
     float tmin[PLANE_SKEW_STEPS];
@@ -186,8 +257,8 @@ static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, siz
             fprintf(stderr, " -> %zu\n", *skew);
         }
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    mmc_pool_event_release(h->prm.device, true, e0);
+    mmc_pool_event_release(h->prm.device, true, e1);
     if (rc == MMC_OK) {
         std::lock_guard<std::mutex> lock(g_skew_mutex);
         g_skew_cache[key] = *skew;
@@ -226,7 +297,6 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
         return fail(nullptr, MMC_ERR_NO_DEVICE, "mmc_create: no HIP device available");
     if (p->device < 0 || p->device >= ndev)
         return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: device ordinal out of range");
-
     mmc_handle *h = new mmc_handle();
     h->prm = *p;
     auto bail = [&](int code) {
@@ -238,8 +308,11 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     if (p->stream) {
         h->stream = (hipStream_t)p->stream;
     } else {
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-            h->err = "hipStreamCreate failed";
+        h->stream = mmc_pool_stream_acquire(p->device);
+        if (!h->stream) {
+            int built = 0, rt = 0;
+            mmc_hip_versions(&built, &rt);
+            h->err = "hipStreamCreate failed (library built against HIP " + std::to_string(built) + ", runtime " + std::to_string(rt) + ")";
             return bail(MMC_ERR_HIP);
         }
         h->own_stream = true;
@@ -334,9 +407,9 @@ extern "C" int mmc_destroy(mmc_handle *h) {
     for (void *p : h->allocs) hipFree(p);
     for (void *p : h->eallocs) hipFree(p);
     if (h->a.ovf_idx) hipFree(h->a.ovf_idx);
-    for (hipEvent_t e : h->events) hipEventDestroy(e);
-    for (hipEvent_t e : h->sweep_events) hipEventDestroy(e);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    for (hipEvent_t e : h->events) mmc_pool_event_release(h->prm.device, true, e);
+    for (hipEvent_t e : h->sweep_events) mmc_pool_event_release(h->prm.device, true, e);
+    if (h->own_stream && h->stream) mmc_pool_stream_release(h->prm.device, h->stream);      // idle: synchronised above
     delete h;
     return MMC_OK;
 }
@@ -833,7 +906,7 @@ extern "C" int mmc_h_partials(mmc_handle *h, double out[2]) {
     int rc = use_device(h); if (rc) return rc;
     if ((rc = zero_sums(h))) return rc;
     HIPCHK(h, mmc_launch_h_partials(h->g, h->a, h->stream));
-    return read_sums(h, 6, 2, out);
+    return read_sums(h, SUM_H, 2, out);
 }
 
 extern "C" int mmc_set_h(mmc_handle *h, float value) {
@@ -928,9 +1001,12 @@ static int sweep_prof_begin(mmc_handle *h, int kind, hipEvent_t **ev) {
     *ev = nullptr;
     if (!h->profiling || h->sweep_used >= SWEEP_PROF_MAX) return MMC_OK;
     if (h->sweep_events.size() < 2 * (h->sweep_used + 1)) {
-        hipEvent_t e0, e1;
-        HIPCHK(h, hipEventCreate(&e0));
-        HIPCHK(h, hipEventCreate(&e1));
+        hipEvent_t e0 = mmc_pool_event_acquire(h->prm.device, true), e1 = mmc_pool_event_acquire(h->prm.device, true);
+        if (!e0 || !e1) {
+            mmc_pool_event_release(h->prm.device, true, e0);
+            mmc_pool_event_release(h->prm.device, true, e1);
+            return fail(h, MMC_ERR_HIP, "sweep profiling: hipEventCreate failed");
+        }
         h->sweep_events.push_back(e0);
         h->sweep_events.push_back(e1);
         h->sweep_kinds.push_back(kind);
@@ -1030,6 +1106,87 @@ extern "C" int mmc_halo_info(mmc_handle *h, mmc_halo *out) {
     return MMC_OK;
 }
 
+// ---- diagnostics: primal and dual objective, gap, optimality residuals -------------------------
+
+extern "C" int mmc_set_diagnostics(mmc_handle *h, int mode) {
+    REQUIRE_HANDLE(h);
+    if (mode < MMC_DIAG_OFF || mode > MMC_DIAG_ALWAYS) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_diagnostics: unknown mode");
+    h->diagnostics = mode;
+    return MMC_OK;
+}
+
+extern "C" int mmc_problem_size(const mmc_handle *h, double *n_primal, double *n_dual) {
+    if (!h) return MMC_ERR_INVALID_ARG;
+    const Geom &g = h->g;
+    const double M = (double)h->L * g.N, m = (double)h->L * g.n;
+    if (n_primal) *n_primal = g.model == MODEL_IC ? 2.0 * M : M;
+    if (n_dual) *n_dual = m + (g.model == MODEL_IC ? 6.0 * M : 3.0 * M) +
+                          ((g.model == MODEL_IC && g.fixed && g.frame_begin == 0) ? 2.0 * g.N : 0.0);
+    return MMC_OK;
+}
+
+extern "C" int mmc_state_halo_info(mmc_handle *h, mmc_halo *out) {
+    REQUIRE_HANDLE(h);
+    if (!out) return fail(h, MMC_ERR_INVALID_ARG, "mmc_state_halo_info: null output");
+    const Geom &g = h->g;
+    const Arrays &a = h->a;
+    memset(out, 0, sizeof(*out));
+    out->frame_bytes = (uint64_t)g.N * sizeof(float);
+    const bool ic = g.model == MODEL_IC;
+    const size_t N = (size_t)g.N;
+    if (h->has_prev) {
+        out->send_prev[0] = a.u + N;
+        out->send_prev[1] = ic ? a.w + N : nullptr;
+    }
+    if (h->has_next) {
+        out->recv_next[0] = a.u + N * (size_t)(h->L + 1);
+        out->recv_next[1] = ic ? a.w + N * (size_t)(h->L + 1) : nullptr;
+    }
+    return MMC_OK;
+}
+
+extern "C" int mmc_diag_partials(mmc_handle *h, double out[MMC_NUM_DIAG]) {
+    REQUIRE_HANDLE(h);
+    if (!out) return fail(h, MMC_ERR_INVALID_ARG, "mmc_diag_partials: null output");
+    int rc = check_range(h, 0, h->L); if (rc) return rc;
+    if ((rc = use_device(h))) return rc;
+    if ((rc = zero_sums(h))) return rc;
+    Arrays e = h->a;
+    e.ub = h->a.u; e.wb = h->a.w;     // K x at the iterate, not at xbar
+    HIPCHK(h, mmc_launch_dual(h->g, e, 0, h->L, MODE_ENERGY, false, h->stream));
+    HIPCHK(h, mmc_launch_primal(h->g, h->a, 0, h->L, MODE_DUALOBJ, false, h->stream));
+    HIPCHK(h, mmc_launch_dual_linear(h->g, h->a, h->stream));
+    if ((rc = read_sums(h, SUM_ENERGY, 4, out))) return rc;
+    if ((rc = read_sums(h, SUM_DUALOBJ, 5, out + 4))) return rc;
+    return MMC_OK;
+}
+
+static void clear_diag(mmc_stats *st) {
+    const double nan = std::nan("");
+    st->primal_energy = st->dual_energy = st->gap = st->dual_infeasibility = nan;
+    st->opt_res_primal = st->opt_res_dual = st->norm_KTy = st->norm_Kx = nan;
+}
+
+extern "C" int mmc_stats_from_diag(const double d[MMC_NUM_DIAG], double n_primal, double n_dual, float tol, mmc_stats *st) {
+    if (!d || !st) return 0;
+    st->primal_energy = d[0] + d[1];
+    st->dual_energy = -d[8] - d[4];
+    st->gap = st->primal_energy - st->dual_energy;
+    st->dual_infeasibility = d[5];
+    st->norm_Kx = std::sqrt(std::max(d[2], 0.0));
+    st->opt_res_dual = std::sqrt(std::max(d[3], 0.0));
+    st->norm_KTy = std::sqrt(std::max(d[6], 0.0));
+    st->opt_res_primal = std::sqrt(std::max(d[7], 0.0));
+    if (!(tol > 0.f)) return 0;
+    const double t = (double)tol;
+    return st->opt_res_primal <= t * std::sqrt(std::max(n_primal, 0.0)) + t * st->norm_KTy &&
+           st->opt_res_dual <= t * std::sqrt(std::max(n_dual, 0.0)) + t * st->norm_Kx;
+}
+
+static bool diag_wanted(const mmc_handle *h, float tol, mmc_progress_cb cb) {
+    return h->diagnostics == MMC_DIAG_ALWAYS || (h->diagnostics == MMC_DIAG_AUTO && (tol > 0.f || cb));
+}
+
 static void fill_stats(mmc_stats *st, const double s[MMC_NUM_SUMS]) {
     const double tiny = 1e-30;
     st->res_primal = std::sqrt(s[0]) / std::max(std::sqrt(s[1]), tiny);
@@ -1047,6 +1204,10 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
     int rc = use_device(h); if (rc) return rc;
     mmc_stats st;
     memset(&st, 0, sizeof(st));
+    clear_diag(&st);
+    const bool diag = diag_wanted(h, tol, cb);
+    double np = 0.0, nd = 0.0;
+    mmc_problem_size(h, &np, &nd);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const auto t_start = std::chrono::steady_clock::now();
     const Geom &g = h->g;
@@ -1055,8 +1216,8 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
         // one event between consecutive sweeps: e[0] P e[1] D e[2] P e[3] D ...
         const size_t need = (size_t)2 * std::min(max_iters, (int)PROF_MAX_ITERS) + 1;
         while (h->events.size() < need) {
-            hipEvent_t e;
-            HIPCHK(h, hipEventCreate(&e));
+            hipEvent_t e = mmc_pool_event_acquire(h->prm.device, true);
+            if (!e) return fail(h, MMC_ERR_HIP, "mmc_solve: hipEventCreate failed");
             h->events.push_back(e);
         }
     }
@@ -1075,9 +1236,15 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
             double s[MMC_NUM_SUMS];
             if ((rc = read_sums(h, 0, MMC_NUM_SUMS, s))) return rc;
             fill_stats(&st, s);
+            bool stop = tol > 0.f && st.res_primal < tol && st.res_dual < tol;
+            if (diag) {
+                double d[MMC_NUM_DIAG];
+                if ((rc = mmc_diag_partials(h, d))) return rc;
+                stop = mmc_stats_from_diag(d, np, nd, tol, &st) != 0;
+            }
             st.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             if (cb && cb(st.iterations, &st, user)) break;
-            if (tol > 0.f && st.res_primal < tol && st.res_dual < tol) { st.converged = 1; break; }
+            if (stop) { st.converged = 1; break; }
         }
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1141,7 +1308,7 @@ extern "C" int mmc_energy(mmc_handle *h, double *value) {
     e.ub = h->a.u; e.wb = h->a.w;     // evaluate at the iterate, not at xbar
     HIPCHK(h, mmc_launch_dual(h->g, e, 0, h->L, MODE_ENERGY, false, h->stream));
     double s[2];
-    if ((rc = read_sums(h, 4, 2, s))) return rc;
+    if ((rc = read_sums(h, SUM_ENERGY, 2, s))) return rc;
     *value = s[0] + s[1];
     return MMC_OK;
 }

@@ -106,6 +106,22 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 // Scale that projects a vector of squared length n2 onto the ball of radius R.
 __device__ __forceinline__ float ball_scale(float n2, float R) { return n2 > R * R ? R * fast_rsq(n2) : 1.f; }
 
+// Squared distance of d = (K x)_j from the normal cone of the dual constraint set at the dual value,
+// i.e. this row group's share of the dual optimality residual dist(K x, dF*(y))^2.
+// Ball of radius R at g: the cone is {0} inside and {lambda g, lambda >= 0} on the sphere.
+__device__ __forceinline__ float ball_residual2(float dt, float dx, float dy, float gt, float gx, float gy, float R) {
+    const float n2 = gt * gt + gx * gx + gy * gy;
+    float lam = 0.f;
+    if (n2 > 0.f && n2 >= R * R * (1.f - 1e-5f)) lam = fmaxf(dt * gt + dx * gx + dy * gy, 0.f) / n2;
+    const float rt = dt - lam * gt, rx = dx - lam * gx, ry = dy - lam * gy;
+    return rt * rt + rx * rx + ry * ry;
+}
+// Interval [-b, b] at y: the cone is {0} inside, [0, inf) at y = b, (-inf, 0] at y = -b.
+__device__ __forceinline__ float box_residual2(float d, float y, float b) {
+    const float r = y >= b ? fminf(d, 0.f) : (y <= -b ? fmaxf(d, 0.f) : d);
+    return r * r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

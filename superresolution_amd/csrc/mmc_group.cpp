@@ -27,6 +27,7 @@ struct GroupBlock {
     hipStream_t sweep = nullptr;     // the block's own stream (owned by the handle)
     hipStream_t copy = nullptr;      // carries this block's outgoing frames
     mmc_halo halo;
+    mmc_halo state_halo;             // first frame of u, w -> ghost slot of the previous block (diagnostics only)
     // recorded on `sweep`: primal / dual sweep of the iteration finished.
     // recorded on `copy` : this block's xbar has arrived at the previous block / its duals at the next.
     hipEvent_t primal_done = nullptr, dual_done = nullptr, xbar_sent = nullptr, duals_sent = nullptr;
@@ -39,10 +40,12 @@ struct mmc_group {
     bool has_w = false, inited = false, have_state = false;
     float h = 0.f;
     bool have_h = false;
+    int diagnostics = MMC_DIAG_AUTO;
     std::string err;
 };
 
 static thread_local std::string g_group_create_err;
+
 
 static int gfail(mmc_group *g, int code, const std::string &msg) {
     if (g) g->err = msg; else g_group_create_err = msg;
@@ -86,11 +89,15 @@ extern "C" mmc_handle *mmc_group_block_handle(mmc_group *g, int block) {
 
 extern "C" int mmc_group_destroy(mmc_group *g) {
     if (!g) return MMC_OK;
+#ifdef MMC_WATCH
+    mmc_canary_free();
+#endif
     for (GroupBlock &b : g->blocks) {
         if (!b.h) continue;                 // never created: no stream, no events
         if (hipSetDevice(b.device) != hipSuccess) (void)hipGetLastError();
-        if (b.copy) { hipStreamSynchronize(b.copy); hipStreamDestroy(b.copy); }
-        for (hipEvent_t e : {b.primal_done, b.dual_done, b.xbar_sent, b.duals_sent}) if (e) hipEventDestroy(e);
+        // streams and events go back to the per-device pool (they live as long as the process)
+        if (b.copy) { hipStreamSynchronize(b.copy); mmc_pool_stream_release(b.device, b.copy); }
+        for (hipEvent_t e : {b.primal_done, b.dual_done, b.xbar_sent, b.duals_sent}) mmc_pool_event_release(b.device, false, e);
         if (b.h) mmc_destroy(b.h);
     }
     delete g;
@@ -132,6 +139,9 @@ extern "C" int mmc_group_create(const mmc_params *p, int nblocks, const int32_t 
     const int base = g->nc / nblocks, rem = g->nc % nblocks;
     int at = 0;
     g->blocks.resize((size_t)nblocks);
+#ifdef MMC_WATCH
+    mmc_canary_new();       // a chunk of the size class that was seen corrupted, allocated where the block table is
+#endif
     for (int i = 0; i < nblocks; ++i) {
         GroupBlock &b = g->blocks[(size_t)i];
         b.begin = at;
@@ -151,11 +161,15 @@ extern "C" int mmc_group_create(const mmc_params *p, int nblocks, const int32_t 
         int rc = mmc_create(&bp, &b.h);
         if (rc != MMC_OK) return bail(rc, std::string("mmc_group_create: ") + mmc_last_error(nullptr));
         b.sweep = mmc_internal_stream(b.h);
+        WCHK("group: after mmc_create of a block");
         if (hipSetDevice(b.device) != hipSuccess) return bail(MMC_ERR_HIP, "mmc_group_create: hipSetDevice failed");
-        if (hipStreamCreateWithFlags(&b.copy, hipStreamNonBlocking) != hipSuccess) return bail(MMC_ERR_HIP, "mmc_group_create: hipStreamCreate failed");
+        if (!(b.copy = mmc_pool_stream_acquire(b.device))) return bail(MMC_ERR_HIP, "mmc_group_create: hipStreamCreate failed");
+        WCHK("group: after copy stream of a block");
         for (hipEvent_t *e : {&b.primal_done, &b.dual_done, &b.xbar_sent, &b.duals_sent})
-            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(MMC_ERR_HIP, "mmc_group_create: hipEventCreate failed");
-        if (mmc_halo_info(b.h, &b.halo) != MMC_OK) return bail(MMC_ERR_HIP, "mmc_group_create: mmc_halo_info failed");
+            if (!(*e = mmc_pool_event_acquire(b.device, false))) return bail(MMC_ERR_HIP, "mmc_group_create: hipEventCreate failed");
+        WCHK("group: after copy stream and events of a block");
+        if (mmc_halo_info(b.h, &b.halo) != MMC_OK || mmc_state_halo_info(b.h, &b.state_halo) != MMC_OK)
+            return bail(MMC_ERR_HIP, "mmc_group_create: mmc_halo_info failed");
     }
     // direct copies between neighbouring devices where the hardware allows it (xGMI); without
     // peer access hipMemcpyPeerAsync stages through the host and stays correct
@@ -177,7 +191,8 @@ extern "C" int mmc_group_set_lowres(mmc_group *g, const float *f) {
     REQUIRE_GROUP(g);
     if (!f) return gfail(g, MMC_ERR_INVALID_ARG, "mmc_group_set_lowres: null data");
     const size_t n = (size_t)g->prm.ny * g->prm.nx;
-    for (GroupBlock &b : g->blocks) GBLK(g, b, mmc_set_lowres(b.h, f + n * (size_t)b.begin));
+    WCHK("group: entry of set_lowres");
+    for (GroupBlock &b : g->blocks) { GBLK(g, b, mmc_set_lowres(b.h, f + n * (size_t)b.begin)); WCHK("group: after set_lowres of a block"); }
     return MMC_OK;
 }
 
@@ -225,6 +240,44 @@ static int exchange_xbar_now(mmc_group *g) {
     return MMC_OK;
 }
 
+// The diagnostics of mmc_stats for the whole sequence: every block's first frame of the iterate goes to
+// the previous block's ghost slot, then the blocks' partial sums are added up.  Synchronous.
+static int group_diagnostics(mmc_group *g, float tol, mmc_stats *st, bool *stop) {
+    for (GroupBlock &b : g->blocks) {
+        GHIP(g, hipSetDevice(b.device));
+        GHIP(g, hipStreamSynchronize(b.copy));
+        GBLK(g, b, mmc_sync(b.h));
+    }
+    for (size_t i = 1; i < g->blocks.size(); ++i) {
+        GroupBlock &b = g->blocks[i], &pv = g->blocks[i - 1];
+        GHIP(g, hipSetDevice(b.device));
+        for (int k = 0; k < 2; ++k)
+            if (b.state_halo.send_prev[k])
+                GHIP(g, hipMemcpyPeerAsync(pv.state_halo.recv_next[k], pv.device, b.state_halo.send_prev[k], b.device,
+                                           b.state_halo.frame_bytes, b.copy));
+        GHIP(g, hipStreamSynchronize(b.copy));
+    }
+    double d[MMC_NUM_DIAG], np = 0.0, nd = 0.0;
+    for (double &v : d) v = 0.0;
+    for (GroupBlock &b : g->blocks) {
+        double part[MMC_NUM_DIAG], p1 = 0.0, d1 = 0.0;
+        GBLK(g, b, mmc_diag_partials(b.h, part));
+        for (int k = 0; k < MMC_NUM_DIAG; ++k) d[k] += part[k];
+        mmc_problem_size(b.h, &p1, &d1);
+        np += p1;
+        nd += d1;
+    }
+    *stop = mmc_stats_from_diag(d, np, nd, tol, st) != 0;
+    return MMC_OK;
+}
+
+extern "C" int mmc_group_set_diagnostics(mmc_group *g, int mode) {
+    REQUIRE_GROUP(g);
+    for (GroupBlock &b : g->blocks) GBLK(g, b, mmc_set_diagnostics(b.h, mode));
+    g->diagnostics = mode;
+    return MMC_OK;
+}
+
 extern "C" int mmc_group_set_state(mmc_group *g, const float *u, const float *w) {
     REQUIRE_GROUP(g);
     if (u && g->has_w && !w) return gfail(g, MMC_ERR_INVALID_ARG, "mmc_group_set_state: this model needs w");
@@ -253,7 +306,9 @@ extern "C" int mmc_group_set_flexbox_backward_terms(mmc_group *g, int enable) {
 
 extern "C" int mmc_group_init(mmc_group *g) {
     REQUIRE_GROUP(g);
+    WCHK("group: entry of init");
     for (GroupBlock &b : g->blocks) GBLK(g, b, mmc_init(b.h));
+    WCHK("group: after mmc_init of the blocks");
     if (!g->have_h) {
         // h = (sum |W u0|) / (sum |grad u0|) over the whole sequence, MultiframeMotionCoupling.m:431-437
         double s[2] = {0.0, 0.0};
@@ -294,11 +349,15 @@ extern "C" int mmc_group_set_h(mmc_group *g, float value) {
 extern "C" int mmc_group_solve(mmc_group *g, int max_iters, float tol, int check_every,
                                mmc_stats *stats, mmc_progress_cb cb, void *user) {
     REQUIRE_GROUP(g);
+    WCHK("group: entry of solve");
     if (!g->inited) return gfail(g, MMC_ERR_STATE, "No initialization found, run mmc_group_init first.");
     if (max_iters < 0) return gfail(g, MMC_ERR_INVALID_ARG, "mmc_group_solve: negative iteration count");
     if (check_every <= 0) check_every = max_iters > 0 ? max_iters : 1;
     mmc_stats st;
     memset(&st, 0, sizeof(st));
+    st.primal_energy = st.dual_energy = st.gap = st.dual_infeasibility = std::nan("");
+    st.opt_res_primal = st.opt_res_dual = st.norm_KTy = st.norm_Kx = std::nan("");
+    const bool diag = g->diagnostics == MMC_DIAG_ALWAYS || (g->diagnostics == MMC_DIAG_AUTO && (tol > 0.f || cb));
     std::vector<GroupBlock> &B = g->blocks;
     const size_t nb = B.size();
     if (nb == 1) {
@@ -373,9 +432,11 @@ extern "C" int mmc_group_solve(mmc_group *g, int max_iters, float tol, int check
             const double tiny = 1e-30;
             st.res_primal = std::sqrt(s[0]) / std::max(std::sqrt(s[1]), tiny);
             st.res_dual = std::sqrt(s[2]) / std::max(std::sqrt(s[3]), tiny);
+            bool stop = tol > 0.f && st.res_primal < tol && st.res_dual < tol;
+            if (diag) { int rc = group_diagnostics(g, tol, &st, &stop); if (rc) return rc; }
             st.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             if (cb && cb(st.iterations, &st, user)) break;
-            if (tol > 0.f && st.res_primal < tol && st.res_dual < tol) { st.converged = 1; break; }
+            if (stop) { st.converged = 1; break; }
         }
     }
     for (GroupBlock &b : B) {
@@ -392,6 +453,7 @@ extern "C" int mmc_group_get_state(mmc_group *g, float *u, float *w) {
     REQUIRE_GROUP(g);
     if (w && !g->has_w) return gfail(g, MMC_ERR_INVALID_ARG, "mmc_group_get_state: this model has no w");
     const size_t N = (size_t)g->Ny * g->Nx;
+    WCHK("group: entry of get_state");
     for (GroupBlock &b : g->blocks)
         GBLK(g, b, mmc_get_state(b.h, u ? u + N * (size_t)b.begin : nullptr, w ? w + N * (size_t)b.begin : nullptr));
     return MMC_OK;

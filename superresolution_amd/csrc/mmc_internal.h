@@ -8,7 +8,10 @@
 enum { MODEL_IC = 0, MODEL_K1 = 1, MODEL_ADD = 2 };
 // MODE_STEPS_UPD (primal sweep only): the step sizes exactly as MODE_UPDATE derives them (column sums of W
 // from the scatter and the identity bits), where MODE_STEPS reads the cW plane written by mmc_init.
-enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3, MODE_STEPS_UPD = 4 };
+// MODE_ENERGY (dual sweep, evaluated at the iterate): primal energy, |K x|^2 and the dual optimality residual.
+// MODE_DUALOBJ (primal sweep): the K'y terms of the dual objective, |K'y|^2 and the primal optimality residual;
+// writes nothing.
+enum { MODE_UPDATE = 0, MODE_RAW = 1, MODE_STEPS = 2, MODE_ENERGY = 3, MODE_STEPS_UPD = 4, MODE_DUALOBJ = 5 };
 
 // One workgroup of 256 threads owns a TILE_R x TILE_C pixel tile of one frame.
 // Rows are the contiguous axis (column-major frames), so one 64-lane wave
@@ -31,7 +34,14 @@ enum { MMC_WARP_MAX = 2304 }; // floats of the warped frame a tile may stage in 
 enum { MMC_TAP_MR = 4, MMC_TAP_MC = 5, MMC_SRC_MR = 4, MMC_SRC_MC = 4 };
 static_assert((MMC_TILE_R + 1 + 2 * MMC_TAP_MR + 6 + 1) * (MMC_TILE_C + 1 + 2 * MMC_TAP_MC) <= MMC_WARP_MAX, "tap region must fit its LDS buffer");
 enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
-enum { MMC_NUM_SUMS_INT = 8 }; // reduced quantities kept on the device
+// Reduced quantities kept on the device, MMC_SUM_SLOTS partial sums each:
+//   0..3   sum (x+ - x)^2, sum (x+)^2, sum (y+ - y)^2, sum (y+)^2          (update sweeps with reduce)
+//   4..7   regulariser energy, data energy, |K x|^2, dual optimality residual^2   (dual sweep, MODE_ENERGY)
+//   8, 9   sum |W u0|, sum |grad u0|                                       (h)
+//   10..13 sum max(0, -(K'y)_u), sum |(K'y)_w|, |K'y|^2, primal optimality residual^2   (primal sweep, MODE_DUALOBJ)
+//   14     <f, p> (+ <u0, q1> + <w0, q2>)                                  (k_dual_linear)
+enum { MMC_NUM_SUMS_INT = 16 };
+enum { SUM_RES = 0, SUM_ENERGY = 4, SUM_H = 8, SUM_DUALOBJ = 10, SUM_DUALLIN = 14 };
 // MMC_STATIC_MAX_BLOCKS (public header): workgroups of k_h_partials that mmc_h_partials_static has room for
 
 // Division of 0 <= n < 2^31 by a fixed d through one high multiply: n / d = umulhi(n, m) >> s
@@ -133,6 +143,8 @@ struct BicubicTab { float w[MMC_BICUBIC_MAX_ZOOM][MMC_BICUBIC_TAPS]; int first[M
 // u, ub (and w, wb when the model has w) of the local frames <- imresize(f, zoom, 'bicubic')
 hipError_t mmc_launch_bicubic_start(const Geom &g, const Arrays &a, const BicubicTab &tab, hipStream_t s);
 hipError_t mmc_launch_h_partials(const Geom &g, const Arrays &a, hipStream_t s);
+// sums[SUM_DUALLIN] += <f, p> over the local frames (+ <u0, q1> + <w0, q2> on the block that holds the pinned frame)
+hipError_t mmc_launch_dual_linear(const Geom &g, const Arrays &a, hipStream_t s);
 // Streams through 12 per-pixel planes (L+2 frame slots each) with the block walk and access shape of
 // the sweeps and leaves their contents unchanged; times how a placement of the planes performs.
 hipError_t mmc_launch_stream_probe(const Geom &g, float *const planes[12], int nf, bool dual_like, hipStream_t s);
@@ -171,6 +183,29 @@ enum { MMC_SF_BOX_MAX = 6144 };   // largest source rectangle (pixels) the tile 
 // Failure of an entry point that has no handle and must not allocate: `literal` (a string literal)
 // becomes what mmc_last_error(NULL) returns on this thread; returns `code`.
 int mmc_static_fail(int code, const char *literal);
+
+// Streams and events of handles and groups come from a per-device pool that lives as long as the
+// process: a destroyed handle gives them back instead of destroying them, so a session that builds
+// one solver per batch creates each runtime object once.  `device` must be the current device on
+// acquire.  A released stream must be idle (synchronised); a released event may have been recorded.
+// timing = false: hipEventDisableTiming.  Null on failure (message via hipGetLastError).
+hipStream_t mmc_pool_stream_acquire(int device);
+void mmc_pool_stream_release(int device, hipStream_t s);
+hipEvent_t mmc_pool_event_acquire(int device, bool timing);
+void mmc_pool_event_release(int device, bool timing, hipEvent_t e);
+
+#ifdef MMC_WATCH
+// debug builds only (tools/watch/mmc_watch.c)
+extern "C" int mmc_watch_arm(void *addr);
+extern "C" void mmc_watch_disarm(void);
+extern "C" void mmc_watch_check(const char *where);
+extern "C" void mmc_canary_new(void);
+extern "C" void mmc_canary_check(const char *where);
+extern "C" void mmc_canary_free(void);
+#define WCHK(where) mmc_canary_check(where)
+#else
+#define WCHK(where) ((void)0)
+#endif
 
 // Used by the group driver (mmc_group.cpp), which owns one handle per frame block.
 struct mmc_handle;

@@ -22,6 +22,20 @@
 
 #include "mmc_device.h"
 
+// The pieces of the dual objective and of the primal optimality residual that one entry of K'y
+// contributes (G = indicator of [0,1] on u, MultiframeMotionCoupling.m:495; w is free):
+//   d[0] += max(0, -KTu)            G*(-K'y) on u
+//   d[1] += |KTw|                   the dual objective is finite only where this vanishes
+//   d[2] += KTu^2 + KTw^2           |K'y|^2
+//   d[3] += dist(-K'y, dG(x))^2     at u = 0 only KTu < 0 violates, at u = 1 only KTu > 0; all of KTw
+__device__ __forceinline__ void dual_objective_terms(float (&d)[4], float KTu, float KTw, float u) {
+    d[0] += fmaxf(-KTu, 0.f);
+    d[1] += fabsf(KTw);
+    d[2] += KTu * KTu + KTw * KTw;
+    const float ru = u <= 0.f ? fminf(KTu, 0.f) : (u >= 1.f ? fmaxf(KTu, 0.f) : KTu);
+    d[3] += ru * ru + KTw * KTw;
+}
+
 // --------------------------------------------------------------------------
 // primal sweep
 // --------------------------------------------------------------------------
@@ -92,6 +106,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
     const float *cW = FR(a.cW, t);
     const float *p = a.p + (size_t)t * g.n;
     float part[2] = {0.f, 0.f};
+    float dob[4] = {0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int s = 0; s < TILE_R * TILE_C / MMC_THREADS; ++s) {
@@ -140,6 +155,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
             if (MODEL == MODEL_IC) wb[j] = KTw;
             continue;
         }
+        if (MODE == MODE_DUALOBJ) {
+            dual_objective_terms(dob, KTu, KTw, u[j]);
+            continue;
+        }
         const float uo = u[j];
         const float un = fminf(fmaxf(uo - tau_u * KTu, 0.f), 1.f);   // G = ind[0,1], :495
         u[j] = un;
@@ -153,7 +172,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0
             if (REDUCE) { part[0] += (wn - wo) * (wn - wo); part[1] += wn * wn; }
         }
     }
-    if (REDUCE) block_accumulate<2>(part, a.sums, 0);
+    if (MODE == MODE_DUALOBJ) block_accumulate<4>(dob, a.sums, SUM_DUALOBJ);
+    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES);
 }
 
 // --------------------------------------------------------------------------
@@ -243,7 +263,8 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
     // (measured: fewer live registers across the scatter beats hiding their latency).
     auto own_loads = [&](bool grpX, bool grpA, bool grp2, bool grp1) {
         if (!active) return;
-        if (grpX) {
+        if (grpX && MODE == MODE_DUALOBJ) ld4(uo, FR(a.u, t) + j);      // no step sizes in this mode
+        if (grpX && MODE != MODE_DUALOBJ) {
             if (!CWS) ld4(cWv, FR(a.cW, t) + j);
             if (F == 4 && g.cA_margin > 0 && r >= g.cA_margin && r + 4 <= g.Ny - g.cA_margin &&
                 c >= g.cA_margin && c < g.Nx - g.cA_margin && !ABL(128)) {
@@ -400,6 +421,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
 
     own_loads(true, false, false, false);      // u, w, cW, cA: only needed from here on
     float part[2] = {0.f, 0.f};
+    float dob[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         float *u = FR(a.u, t) + j, *w = FR(a.w, t) + j, *ub = FR(a.ub, t) + j, *wb = FR(a.wb, t) + j;
         float tau_u[4], tau_w[4];
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                 }
             }
         };
-        compute_tau();
+        if (MODE != MODE_DUALOBJ) compute_tau();
         if (MODE == MODE_STEPS || MODE == MODE_STEPS_UPD) {
             st4(ub, tau_u);
             if (MODEL == MODEL_IC) st4(wb, tau_w);
@@ -535,6 +557,9 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
             if (MODE == MODE_RAW) {
                 st4(ub, KTu);
                 if (MODEL == MODEL_IC) st4(wb, KTw);
+            } else if (MODE == MODE_DUALOBJ) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dual_objective_terms(dob, KTu[i], KTw[i], uo[i]);
             } else {
                 float un[4], ubn[4];
 #pragma unroll
@@ -559,7 +584,8 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
             }
         }
     }
-    if (REDUCE) block_accumulate<2>(part, a.sums, 0);
+    if (MODE == MODE_DUALOBJ) block_accumulate<4>(dob, a.sums, SUM_DUALOBJ);
+    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES);
 }
 
 // --------------------------------------------------------------------------
@@ -585,6 +611,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) 
     float *g1t = FR(a.g1t, t), *g1x = FR(a.g1x, t), *g1y = FR(a.g1y, t);
     float *g2t = FR(a.g2t, t), *g2x = FR(a.g2x, t), *g2y = FR(a.g2y, t);
     float part[2] = {0.f, 0.f};
+    float diag[2] = {0.f, 0.f};      // MODE_ENERGY: |K x|^2, dual optimality residual^2
 
 #pragma unroll
     for (int s = 0; s < TILE_R * TILE_C / MMC_THREADS; ++s) {
@@ -651,13 +678,23 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) 
             continue;
         }
         if (MODE == MODE_ENERGY) {
+            diag[0] += k1t * k1t + k1x * k1x + k1y * k1y + k2t * k2t + k2x * k2x + k2y * k2y;
             if (MODEL == MODEL_IC) {
                 part[0] += g.radius1 * sqrtf(k1t * k1t + k1x * k1x + k1y * k1y) +
                            g.radius2 * sqrtf(k2t * k2t + k2x * k2x + k2y * k2y);
+                diag[1] += ball_residual2(k1t, k1x, k1y, g1t[j], g1x[j], g1y[j], g.radius1) +
+                           ball_residual2(k2t, k2x, k2y, g2t[j], g2x[j], g2y[j], g.radius2);
+                if (g.fixed && g.frame_begin + t == 0) {      // identity rows of q1, q2: dF* = {x0}
+                    const float du = uc - a.u0[j], dw = wc - a.w0[j];
+                    diag[0] += uc * uc + wc * wc;
+                    diag[1] += du * du + dw * dw;
+                }
             } else if (MODEL == MODEL_K1) {
                 part[0] += g.radius1 * sqrtf(k1t * k1t + k1x * k1x + k1y * k1y);
+                diag[1] += ball_residual2(k1t, k1x, k1y, g1t[j], g1x[j], g1y[j], g.radius1);
             } else {
                 part[0] += g.radius1 * fabsf(k1t) + g.radius2 * sqrtf(k1x * k1x + k1y * k1y);
+                diag[1] += box_residual2(k1t, g1t[j], g.radius1) + ball_residual2(0.f, k1x, k1y, 0.f, g1x[j], g1y[j], g.radius2);
             }
             continue;
         }
@@ -708,8 +745,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) 
             }
         }
     }
-    if (MODE == MODE_ENERGY) { float e[1] = {part[0]}; block_accumulate<1>(e, a.sums, 4); }
-    else if (REDUCE) block_accumulate<2>(part, a.sums, 2);
+    if (MODE == MODE_ENERGY) { float e[4] = {part[0], 0.f, diag[0], diag[1]}; block_accumulate<4>(e, a.sums, SUM_ENERGY); }
+    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES + 2);
 }
 
 // --------------------------------------------------------------------------
@@ -719,6 +756,7 @@ template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0, int nframes) {
     const size_t idx = (size_t)blockIdx.x * MMC_THREADS + threadIdx.x;
     float part[2] = {0.f, 0.f};
+    float diag[2] = {0.f, 0.f};      // MODE_ENERGY: |K x|^2, dual optimality residual^2
     if (idx < (size_t)g.n * nframes) {
         const int t = t0 + (int)(idx / g.n);
         const int i = (int)(idx % g.n);
@@ -742,6 +780,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0
             a.p[o] = sg;
         } else if (MODE == MODE_ENERGY) {
             part[0] = fabsf(acc - a.f[o]);
+            diag[0] = acc * acc;
+            diag[1] = box_residual2(acc - a.f[o], a.p[o], 1.f);
         } else {
             const float po = a.p[o];
             const float pn = fminf(fmaxf(po + sg * (acc - a.f[o]), -1.f), 1.f);
@@ -749,8 +789,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0
             if (REDUCE) { part[0] = (pn - po) * (pn - po); part[1] = pn * pn; }
         }
     }
-    if (MODE == MODE_ENERGY) { float e[1] = {part[0]}; block_accumulate<1>(e, a.sums, 5); }
-    else if (REDUCE) block_accumulate<2>(part, a.sums, 2);
+    if (MODE == MODE_ENERGY) { float e[3] = {part[0], diag[0], diag[1]}; block_accumulate<3>(e, a.sums, SUM_ENERGY + 1); }
+    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES + 2);
 }
 
 // --------------------------------------------------------------------------
@@ -836,7 +876,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
             if (hasx) ld4(wx, wb + j + g.Ny);
             if (r + 4 < g.Ny) wbelow = wb[j + 4];
         }
-        if (MODE == MODE_UPDATE) {
+        if (MODE == MODE_UPDATE || MODE == MODE_ENERGY) {
             // a frame without a pair (the last of the sequence) has no temporal rows: their duals stay 0
             // and their planes are neither read nor written
             const bool tpl = pex || !MMC_SKIP_NOPAIR;
@@ -898,6 +938,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
     if (MODE != MODE_STEPS) __syncthreads();
 
     float part[2] = {0.f, 0.f};
+    float diag[2] = {0.f, 0.f};      // MODE_ENERGY: |K x|^2, dual optimality residual^2
     if (active && nb_lds) {
         const float *own = ubl + (4 * rq - g.oy + wpad) + SR * (lc - g.ox);
         if (hasx) ld4(ux, own + SR);
@@ -972,13 +1013,28 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
         } else if (MODE == MODE_ENERGY) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (MODEL == MODEL_IC)
+                diag[0] += k1t[i] * k1t[i] + k1x[i] * k1x[i] + k1y[i] * k1y[i] + k2t[i] * k2t[i] + k2x[i] * k2x[i] + k2y[i] * k2y[i];
+                if (MODEL == MODEL_IC) {
                     part[0] += g.radius1 * sqrtf(k1t[i] * k1t[i] + k1x[i] * k1x[i] + k1y[i] * k1y[i]) +
                                g.radius2 * sqrtf(k2t[i] * k2t[i] + k2x[i] * k2x[i] + k2y[i] * k2y[i]);
-                else if (MODEL == MODEL_K1)
+                    diag[1] += ball_residual2(k1t[i], k1x[i], k1y[i], o1t[i], o1x[i], o1y[i], g.radius1) +
+                               ball_residual2(k2t[i], k2x[i], k2y[i], o2t[i], o2x[i], o2y[i], g.radius2);
+                } else if (MODEL == MODEL_K1) {
                     part[0] += g.radius1 * sqrtf(k1t[i] * k1t[i] + k1x[i] * k1x[i] + k1y[i] * k1y[i]);
-                else
+                    diag[1] += ball_residual2(k1t[i], k1x[i], k1y[i], o1t[i], o1x[i], o1y[i], g.radius1);
+                } else {
                     part[0] += g.radius1 * fabsf(k1t[i]) + g.radius2 * sqrtf(k1x[i] * k1x[i] + k1y[i] * k1y[i]);
+                    diag[1] += box_residual2(k1t[i], o1t[i], g.radius1) + ball_residual2(0.f, k1x[i], k1y[i], 0.f, o1x[i], o1y[i], g.radius2);
+                }
+            }
+            if (MODEL == MODEL_IC && g.fixed && g.frame_begin + t == 0) {      // identity rows of q1, q2: dF* = {x0}
+                float x0u[4], x0w[4];
+                ld4(x0u, a.u0 + j); ld4(x0w, a.w0 + j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    diag[0] += uc[i] * uc[i] + wc[i] * wc[i];
+                    diag[1] += (uc[i] - x0u[i]) * (uc[i] - x0u[i]) + (wc[i] - x0w[i]) * (wc[i] - x0w[i]);
+                }
             }
         } else {
             float n1t[4], n1x[4], n1y[4];
@@ -1058,8 +1114,8 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
         const size_t o = (size_t)t * g.n + (owner ? R + g.ny * C : 0);
         float po = 0.f, fo = 0.f, sg = 0.f;
         if (owner) {
-            if (MODE == MODE_UPDATE) { po = a.p[o]; sg = a.sigp[R + g.ny * C]; }
-            if (MODE == MODE_UPDATE || MODE == MODE_ENERGY) fo = a.f[o];
+            if (MODE == MODE_UPDATE) sg = a.sigp[R + g.ny * C];
+            if (MODE == MODE_UPDATE || MODE == MODE_ENERGY) { po = a.p[o]; fo = a.f[o]; }
         }
         const int mq = g.MPq >> 2;
         float s = 0.f;
@@ -1079,6 +1135,8 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
                 a.p[o] = s;
             } else if (MODE == MODE_ENERGY) {
                 epart += fabsf(s - fo);
+                diag[0] += s * s;
+                diag[1] += box_residual2(s - fo, po, 1.f);
             } else {
                 const float pn = fminf(fmaxf(po + sg * (s - fo), -1.f), 1.f);
                 a.p[o] = pn;
@@ -1130,6 +1188,8 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
             a.p[o] = acc;
         } else if (MODE == MODE_ENERGY) {
             epart += fabsf(acc - a.f[o]);
+            diag[0] += acc * acc;
+            diag[1] += box_residual2(acc - a.f[o], a.p[o], 1.f);
         } else {
             const float po = a.p[o];
             const float pn = fminf(fmaxf(po + sg * (acc - a.f[o]), -1.f), 1.f);
@@ -1137,8 +1197,8 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
             if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; }
         }
     }
-    if (MODE == MODE_ENERGY) { float e[2] = {part[0], epart}; block_accumulate<2>(e, a.sums, 4); }
-    else if (REDUCE) block_accumulate<2>(part, a.sums, 2);
+    if (MODE == MODE_ENERGY) { float e[4] = {part[0], epart, diag[0], diag[1]}; block_accumulate<4>(e, a.sums, SUM_ENERGY); }
+    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES + 2);
 }
 
 // --------------------------------------------------------------------------
@@ -1379,8 +1439,22 @@ __global__ __launch_bounds__(MMC_THREADS) void k_h_partials(Geom g, Arrays a, do
         const float s = block_sum<2>(part);
         if (threadIdx.x < 2) out[2 * ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) + threadIdx.x] = (double)s;
     } else {
-        block_accumulate<2>(part, a.sums, 6);
+        block_accumulate<2>(part, a.sums, SUM_H);
     }
+}
+
+// sums[SUM_DUALLIN] += <f, p> over the local frames, plus <u0, q1> + <w0, q2> on the block that holds
+// the pinned first frame: the linear parts of F* (MultiframeMotionCoupling.m:496, :563-564).
+__global__ __launch_bounds__(MMC_THREADS) void k_dual_linear(Geom g, Arrays a) {
+    const size_t i = (size_t)blockIdx.x * MMC_THREADS + threadIdx.x;
+    const size_t np = (size_t)g.L * g.n;
+    float part[1] = {0.f};
+    if (i < np) part[0] = a.f[i] * a.p[i];
+    else if (i < np + (size_t)g.N && g.model == MODEL_IC && g.fixed && g.frame_begin == 0) {
+        const size_t j = i - np;
+        part[0] = a.u0[j] * a.q1[j] + a.w0[j] * a.q2[j];
+    }
+    block_accumulate<1>(part, a.sums, SUM_DUALLIN);
 }
 
 // One workgroup: result[i] = sum over b < nblocks of part[2b + i], i = 0, 1, in an order that
@@ -1492,6 +1566,7 @@ template <int MODEL>
 static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     dim3 grid(g.ntiles, nf), block(MMC_THREADS);
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal<MODEL, MODE_RAW, false>), grid, block, 0, s, g, a, t0);
+    else if (mode == MODE_DUALOBJ) hipLaunchKernelGGL((k_primal<MODEL, MODE_DUALOBJ, false>), grid, block, 0, s, g, a, t0);
     else if (mode == MODE_STEPS || mode == MODE_STEPS_UPD)      // the scalar kernel always reads the cW plane
         hipLaunchKernelGGL((k_primal<MODEL, MODE_STEPS, false>), grid, block, 0, s, g, a, t0);
     else if (reduce) hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, true>), grid, block, 0, s, g, a, t0);
@@ -1522,6 +1597,7 @@ static void launch_primal4_m(const Geom &g0, const Arrays &a, int t0, int nf, in
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const size_t lds = (size_t)(6 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float) + lds_pad();
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_DUALOBJ) hipLaunchKernelGGL((k_primal4<MODEL, MODE_DUALOBJ, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS_UPD) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS_UPD, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0, nf);
@@ -1666,6 +1742,12 @@ hipError_t mmc_launch_fold_occ(const Geom &g, float *vx, const uint8_t *occ, siz
 hipError_t mmc_launch_bicubic_start(const Geom &g, const Arrays &a, const BicubicTab &tab, hipStream_t s) {
     dim3 grid((g.N + MMC_THREADS - 1) / MMC_THREADS, g.L), block(MMC_THREADS);
     hipLaunchKernelGGL(k_bicubic_start, grid, block, 0, s, g, a, tab);
+    return hipGetLastError();
+}
+
+hipError_t mmc_launch_dual_linear(const Geom &g, const Arrays &a, hipStream_t s) {
+    const size_t total = (size_t)g.L * g.n + ((g.model == MODEL_IC && g.fixed && g.frame_begin == 0) ? (size_t)g.N : 0);
+    hipLaunchKernelGGL(k_dual_linear, dim3((unsigned)((total + MMC_THREADS - 1) / MMC_THREADS)), dim3(MMC_THREADS), 0, s, g, a);
     return hipGetLastError();
 }
 

@@ -157,7 +157,10 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_tile(Geom g, SfArrays a
     if (REDUCE) block_accumulate<2>(part, a.sums, 2);
 }
 
-// q <- projection of q + s G ub onto ||q_j|| <= alpha  (sum_norm2(2,false,'ind_leq0',1/alpha,...), :163)
+// q <- projection of (q + s G ub) / (1 + s delta/alpha) onto ||q_j|| <= alpha: the prox of
+// ind{||q_j|| <= alpha} + (delta/alpha)/2 ||q_j||^2, i.e. sum_norm2(2,false,'ind_leq0',1/alpha,1,1,0,huber_eps/alpha)
+// of singleframeMotionSR_unger_prost.m:163 (Huber-smoothed TV); delta = 0 is the plain projection of
+// singleframeMotionSR_mitzel_prost.m:163.
 template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_q(Geom g, SfArrays a, const float *__restrict__ img) {
     const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(MMC_THREADS) void k_sf_dual_q(Geom g, SfArrays a, c
             const float rs = fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f);
             const float sg = rs > 0.f ? 1.f / rs : 1.f;
             const float ox = a.qx[j], oy = a.qy[j];
-            float nx = ox + sg * dx, ny = oy + sg * dy;
+            const float shrink = 1.f / (1.f + sg * a.delta / a.alpha);
+            float nx = (ox + sg * dx) * shrink, ny = (oy + sg * dy) * shrink;
             const float n2 = nx * nx + ny * ny;
             if (n2 > a.alpha * a.alpha) { const float sc = a.alpha / sqrtf(n2); nx *= sc; ny *= sc; }
             a.qx[j] = nx; a.qy[j] = ny;

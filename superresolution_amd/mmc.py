@@ -264,8 +264,9 @@ class MultiframeMotionCoupling(object):
         cb = None
         if self.verbose > 0:
             def cb(it, d):
-                print("  it %6d  res_primal %.3e  res_dual %.3e  (%.2f s)" %
-                      (it, d["res_primal"], d["res_dual"], d["seconds"]))
+                # what prost prints 'num_cback_calls' = 5 times per solve (:357-359)
+                print("  it %6d  energy %.6e  gap %.3e  res_primal %.3e  res_dual %.3e  (%.2f s)" %
+                      (it, d["primal_energy"], d["gap"], d["opt_res_primal"], d["opt_res_dual"], d["seconds"]))
                 return False
         every = max(self._opts["max_iters"] // 5, 1) if self.verbose > 0 else self.check_every   # num_cback_calls 5, :358
         every = min(every, self.check_every) if self.check_every > 0 else every

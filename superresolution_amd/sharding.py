@@ -61,8 +61,13 @@ def halo_tensors(solver):
     def view(p):
         return None if not p else torch.as_tensor(DeviceBuffer(p, count), device=dev)
 
-    return {name: [view(getattr(hl, name)[i]) for i in range(2)]
-            for name in ("send_prev", "recv_next", "send_next", "recv_prev")}
+    out = {name: [view(getattr(hl, name)[i]) for i in range(2)]
+           for name in ("send_prev", "recv_next", "send_next", "recv_prev")}
+    # first frame of the iterate (u, w) -> ghost slot of the previous block: needed by the diagnostics only
+    sh = solver.state_halo_info()
+    out["state_send_prev"] = [view(sh.send_prev[i]) for i in range(2)]
+    out["state_recv_next"] = [view(sh.recv_next[i]) for i in range(2)]
+    return out
 
 
 def require_torch_stream(solver):
@@ -135,6 +140,12 @@ class HaloExchanger(object):
         """xbar of the first local frame -> previous rank; ghost of the next rank's first frame <- next."""
         return self._start("send_prev", self.prev, "recv_next", self.next)
 
+    def start_state(self):
+        """u, w of the first local frame -> previous rank's ghost slot (before the diagnostics passes)."""
+        if "state_send_prev" not in self.t:
+            return None
+        return self._start("state_send_prev", self.prev, "state_recv_next", self.next)
+
     def start_dual(self):
         """temporal duals of the last local frame -> next rank; ghost of the previous rank's <- previous."""
         return self._start("send_next", self.next, "recv_prev", self.prev)
@@ -161,6 +172,18 @@ def allreduce_sums(values, device=None):
     return t.cpu().numpy()
 
 
+def stats_from_diag(d, n_primal, n_dual, tol=0.0):
+    """The diagnostics of mmc_stats from the MMC_NUM_DIAG sums of the whole sequence (the formula of
+    mmc_stats_from_diag in the C ABI) and whether they pass the absolute + relative residual test."""
+    out = {"primal_energy": float(d[0] + d[1]), "dual_energy": float(-d[8] - d[4]), "dual_infeasibility": float(d[5]),
+           "norm_Kx": float(np.sqrt(max(d[2], 0.0))), "opt_res_dual": float(np.sqrt(max(d[3], 0.0))),
+           "norm_KTy": float(np.sqrt(max(d[6], 0.0))), "opt_res_primal": float(np.sqrt(max(d[7], 0.0)))}
+    out["gap"] = out["primal_energy"] - out["dual_energy"]
+    passes = tol > 0 and (out["opt_res_primal"] <= tol * np.sqrt(max(n_primal, 0.0)) + tol * out["norm_KTy"] and
+                          out["opt_res_dual"] <= tol * np.sqrt(max(n_dual, 0.0)) + tol * out["norm_Kx"])
+    return out, bool(passes)
+
+
 def sharded_h(engine, device=None):
     """h = sum|W u0| / sum|grad u0| over the whole sequence (MultiframeMotionCoupling.m:431-437)."""
     s = allreduce_sums(engine.h_partials(), device)
@@ -169,12 +192,15 @@ def sharded_h(engine, device=None):
     return float(s[0] / s[1])
 
 
-def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=None, callback=None):
+def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=None, callback=None, diagnostics=None):
     """The loop of mmc_solve for a block with neighbours.
 
     `engine` provides L, sweep_primal(t0,t1,reduce), sweep_dual(t0,t1,reduce),
     sums_reset(), sums_read() and sync(); FrameBlockSolver does.  Ghost duals
     start at zero on both sides, matching the zero start of the duals.
+    diagnostics: evaluate energies, gap and optimality residuals at every check and stop on the
+    residual test (see mmc_stats in include/mmc_hip.h); None = when there is a tolerance or a
+    callback, as mmc_solve does.  Needs engine.diag_partials() and engine.problem_size().
     """
     L = engine.L
     if getattr(exchanger, "on_device", False) and hasattr(engine, "params"):
@@ -184,6 +210,8 @@ def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=N
     if check_every <= 0:
         check_every = max(max_iters, 1)
     stats = {"iterations": 0, "converged": False, "res_primal": 0.0, "res_dual": 0.0}
+    if diagnostics is None:
+        diagnostics = (tol > 0 or callback is not None) and hasattr(engine, "diag_partials")
     reqs_dual = None
     for it in range(max_iters):
         check = ((it + 1) % check_every == 0) or it == max_iters - 1
@@ -213,10 +241,19 @@ def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=N
             tiny = 1e-30
             stats["res_primal"] = float(np.sqrt(s[0]) / max(np.sqrt(s[1]), tiny))
             stats["res_dual"] = float(np.sqrt(s[2]) / max(np.sqrt(s[3]), tiny))
+            done = tol > 0 and stats["res_primal"] < tol and stats["res_dual"] < tol
+            if diagnostics:
+                # the read-only passes need the ghost duals of this iteration and the neighbour's iterate
+                exchanger.wait(reqs_dual)
+                reqs_dual = None
+                exchanger.wait(exchanger.start_state())
+                d = allreduce_sums(np.concatenate([engine.diag_partials(), engine.problem_size()]), device)
+                more, done = stats_from_diag(d[:-2], d[-2], d[-1], tol)
+                stats.update(more)
             stop = callback(it + 1, stats) if callback is not None else False
             if stop:
                 break
-            if tol > 0 and stats["res_primal"] < tol and stats["res_dual"] < tol:
+            if done:
                 stats["converged"] = True
                 break
     exchanger.wait(reqs_dual)

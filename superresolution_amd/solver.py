@@ -188,16 +188,14 @@ class FrameBlockSolver(object):
         if callback is not None:
             def _cb(it, stp, _user):
                 s = stp.contents
-                return int(bool(callback(it, {"res_primal": s.res_primal, "res_dual": s.res_dual,
-                                              "seconds": s.solve_seconds})))
+                return int(bool(callback(it, s.as_dict())))
             cb = _capi.PROGRESS_CB(_cb)
         else:
             cb = _capi.PROGRESS_CB()
         self._cb_keepalive = cb
         self._check(self._lib.mmc_solve(self._h, int(max_iters), float(tol), int(check_every),
                                         C.byref(st), cb, None))
-        return {"iterations": st.iterations, "converged": bool(st.converged),
-                "res_primal": st.res_primal, "res_dual": st.res_dual, "seconds": st.solve_seconds}
+        return st.as_dict()
 
     def sweep_primal(self, t0, t1, reduce=False):
         self._check(self._lib.mmc_sweep_primal(self._h, int(t0), int(t1), int(reduce)))
@@ -220,6 +218,34 @@ class FrameBlockSolver(object):
 
     def sync(self):
         self._check(self._lib.mmc_sync(self._h))
+
+    # -- diagnostics: energies, gap, optimality residuals ----------------------
+    def set_diagnostics(self, mode):
+        """_capi.DIAG_OFF / DIAG_AUTO (default: when the solve has a tolerance or a callback) / DIAG_ALWAYS."""
+        self._check(self._lib.mmc_set_diagnostics(self._h, int(mode)))
+
+    def diag_partials(self):
+        """This block's share of the MMC_NUM_DIAG sums at the current iterate and duals (synchronises)."""
+        out = (C.c_double * _capi.MMC_NUM_DIAG)()
+        self._check(self._lib.mmc_diag_partials(self._h, out))
+        return np.array(list(out), dtype=np.float64)
+
+    def state_halo_info(self):
+        hl = _capi.mmc_halo()
+        self._check(self._lib.mmc_state_halo_info(self._h, C.byref(hl)))
+        return hl
+
+    def problem_size(self):
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.mmc_problem_size(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def diagnostics(self, tol=0.0):
+        """Energies, gap and optimality residuals of a block without neighbours, as a dict, plus
+        'passes' (the residual test for tol)."""
+        if self.has_prev or self.has_next:
+            raise MMCError(-2, "diagnostics(): this block has neighbours; add diag_partials() up over the blocks")
+        return stats_from_diag(self._lib, self.diag_partials(), *self.problem_size(), tol=tol)
 
     def set_profiling(self, enable=True):
         self._check(self._lib.mmc_set_profiling(self._h, int(bool(enable))))
@@ -301,6 +327,18 @@ class FrameBlockSolver(object):
         tw = np.empty(N * L, np.float32) if self.has_w else None
         self._check(self._lib.mmc_debug_steps_update(self._h, fptr(tu), fptr(tw)))
         return tu, tw
+
+
+def stats_from_diag(lib, diag, n_primal, n_dual, tol=0.0):
+    """The diagnostics fields of mmc_stats from sums added up over all blocks (mmc_stats_from_diag)."""
+    st = _capi.mmc_stats()
+    d = (C.c_double * _capi.MMC_NUM_DIAG)(*[float(x) for x in diag])
+    passes = lib.mmc_stats_from_diag(d, float(n_primal), float(n_dual), float(tol), C.byref(st))
+    out = {k: v for k, v in st.as_dict().items()
+           if k in ("primal_energy", "dual_energy", "gap", "dual_infeasibility", "opt_res_primal", "opt_res_dual",
+                    "norm_KTy", "norm_Kx")}
+    out["passes"] = bool(passes)
+    return out
 
 
 class SequenceGroupSolver(object):
@@ -446,6 +484,9 @@ class SequenceGroupSolver(object):
     def set_flexbox_backward_terms(self, enable=True):
         self._check(self._lib.mmc_group_set_flexbox_backward_terms(self._g, int(bool(enable))))
 
+    def set_diagnostics(self, mode):
+        self._check(self._lib.mmc_group_set_diagnostics(self._g, int(mode)))
+
     def init(self):
         self._check(self._lib.mmc_group_init(self._g))
 
@@ -464,16 +505,14 @@ class SequenceGroupSolver(object):
         if callback is not None:
             def _cb(it, stp, _user):
                 s = stp.contents
-                return int(bool(callback(it, {"res_primal": s.res_primal, "res_dual": s.res_dual,
-                                              "seconds": s.solve_seconds})))
+                return int(bool(callback(it, s.as_dict())))
             cb = _capi.PROGRESS_CB(_cb)
         else:
             cb = _capi.PROGRESS_CB()
         self._cb_keepalive = cb
         self._check(self._lib.mmc_group_solve(self._g, int(max_iters), float(tol), int(check_every),
                                               C.byref(st), cb, None))
-        return {"iterations": st.iterations, "converged": bool(st.converged),
-                "res_primal": st.res_primal, "res_dual": st.res_dual, "seconds": st.solve_seconds}
+        return st.as_dict()
 
     def get_state(self):
         u = np.empty((self.Ny, self.Nx, self.nc), dtype=np.float32, order="F")

@@ -1,0 +1,174 @@
+"""The diagnostics of mmc_stats (primal and dual objective, gap, optimality residuals) against the oracle's
+model-level definitions (oracle.primal_energy / dual_terms / optimality_residuals) at equal iteration
+counts, for every model, for the kernels outside the row-quad form, for a pinned first frame and for a
+sequence cut into blocks; and the stopping test built on them."""
+import numpy as np
+import pytest
+
+import mmc_oracle as orc
+from helpers import make_case
+
+pytestmark = pytest.mark.gpu
+KBLUR = orc.fspecial_gaussian(7, np.sqrt(0.6))
+
+
+def oracle_stats(P, x, y):
+    t = orc.dual_terms(P, y)
+    rp, rd, nkty, nkx = orc.optimality_residuals(P, x, y)
+    pe = orc.primal_energy(P, x)
+    de = orc.dual_energy(P, y)
+    return {"primal_energy": pe, "dual_energy": de, "gap": pe - de, "dual_infeasibility": t["infeas_w"],
+            "opt_res_primal": rp, "opt_res_dual": rd, "norm_KTy": nkty, "norm_Kx": nkx}
+
+
+def assert_stats_close(st, ref, scale=1.0):
+    pe = abs(ref["primal_energy"])
+    assert abs(st["primal_energy"] - ref["primal_energy"]) < 1e-4 * scale * pe
+    assert abs(st["dual_energy"] - ref["dual_energy"]) < 2e-4 * scale * pe
+    assert abs(st["gap"] - ref["gap"]) < 1e-3 * scale * abs(ref["gap"]) + 2e-4 * scale * pe
+    assert abs(st["dual_infeasibility"] - ref["dual_infeasibility"]) < 1e-3 * scale * ref["dual_infeasibility"] + 1e-5
+    assert abs(st["norm_Kx"] - ref["norm_Kx"]) < 1e-4 * scale * ref["norm_Kx"]
+    assert abs(st["norm_KTy"] - ref["norm_KTy"]) < 1e-3 * scale * ref["norm_KTy"]
+    assert abs(st["opt_res_primal"] - ref["opt_res_primal"]) < 5e-3 * scale * ref["opt_res_primal"]
+    # which duals sit exactly on their spheres is decided in float32 on the device
+    assert abs(st["opt_res_dual"] - ref["opt_res_dual"]) < 5e-2 * scale * ref["opt_res_dual"]
+
+
+def make_solver(P, f, v, occ, kappa, direction, factor=4, k=KBLUR, sampling="average", **kw):
+    from superresolution_amd.solver import FrameBlockSolver
+    ny, nx, nc = f.shape
+    s = FrameBlockSolver(ny, nx, factor, nc, alpha=P.alpha, kappa=kappa, h=0.0, flow_direction=direction, sampling=sampling, **kw)
+    s.set_lowres(f); s.set_blur(k); s.set_flow(v, occ); s.set_state(P.u_up, P.u_up)
+    return s
+
+
+@pytest.mark.parametrize("kappa,direction", [(0.25, "backward"), (0.25, "forward-backward"), (1.0, "forward"), (float("nan"), "backward")])
+def test_diagnostics_match_the_oracle(kappa, direction):
+    from superresolution_amd import _capi
+    f, v, occ = make_case(71, 16, 12, 4, flow="smooth", flow_scale=2.0, with_occ=True)      # 64 x 48: quad kernels, several tiles
+    P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
+    s = make_solver(P, f, v, occ, kappa, direction)
+    s.init()
+    s.set_diagnostics(_capi.DIAG_ALWAYS)
+    seen = []
+    st = s.solve(90, 0.0, 30, callback=lambda it, d: seen.append((it, dict(d))) and False)
+    assert [it for it, _ in seen] == [30, 60, 90]
+    x, y = P.x0, P.y0
+    for it, d in seen:
+        x, y, _ = orc.pdhg(P, 30, x, y)
+        assert_stats_close(d, oracle_stats(P, x, y))
+    assert st["gap"] == seen[-1][1]["gap"]
+    # direct call on the handle gives the same numbers as the solve reported last
+    d2 = s.diagnostics()
+    assert abs(d2["gap"] - st["gap"]) < 1e-9 * abs(st["primal_energy"]) and not d2["passes"]
+    # without diagnostics the second group is NaN and the iterate is bit-for-bit the same
+    u1, w1 = s.get_state()
+    s2 = make_solver(P, f, v, occ, kappa, direction)
+    s2.init()
+    s2.set_diagnostics(_capi.DIAG_OFF)
+    st2 = s2.solve(90, 0.0, 30, callback=lambda it, d: False)
+    assert np.isnan(st2["gap"]) and np.isnan(st2["opt_res_primal"]) and st2["res_primal"] == st["res_primal"]
+    u2, w2 = s2.get_state()
+    assert np.array_equal(u1, u2) and (w1 is None or np.array_equal(w1, w2))
+    s.close(); s2.close()
+
+
+def test_gap_is_nonnegative_where_the_dual_is_feasible_and_shrinks():
+    """kappa = 1 and the additive model have no free variable: the reported dual value is a true lower
+    bound of the optimal energy, so the gap cannot be negative; it shrinks along the iteration."""
+    from superresolution_amd import _capi
+    f, v, occ = make_case(72, 16, 16, 3, flow="smooth", flow_scale=1.5)
+    for kappa in (1.0, float("nan")):
+        P = orc.build_problem(f, v, kappa=kappa, flowDirection="backward", k=KBLUR)
+        s = make_solver(P, f, v, None, kappa, "backward")
+        s.init()
+        s.set_diagnostics(_capi.DIAG_ALWAYS)
+        gaps = []
+        s.solve(1500, 0.0, 300, callback=lambda it, d: gaps.append(d["gap"]) and False)
+        assert all(g >= -1e-5 * abs(P.M) * 1e-3 for g in gaps)
+        assert all(a > b for a, b in zip(gaps, gaps[1:])) and gaps[-1] < 0.05 * gaps[0]
+        s.close()
+
+
+@pytest.mark.parametrize("case", ["zoom2", "zoom3", "rows_not_multiple_of_4", "fixed_frame"])
+def test_diagnostics_on_the_other_kernel_paths(case):
+    from superresolution_amd import _capi
+    kw = {}
+    factor, sampling, k = 4, "average", KBLUR
+    if case == "zoom2":
+        f, v, occ = make_case(73, 32, 24, 3, factor=2, flow="smooth", flow_scale=1.5)
+        factor, sampling = 2, "stride"
+    elif case == "zoom3":
+        f, v, occ = make_case(74, 20, 16, 3, factor=3, flow="smooth", flow_scale=1.5)
+        factor, sampling, k = 3, "stride", orc.fspecial_gaussian(5, 0.8)
+    elif case == "rows_not_multiple_of_4":
+        f, v, occ = make_case(75, 13, 10, 3, factor=3, flow="smooth", flow_scale=1.5)      # 39 rows
+        factor, sampling = 3, "stride"
+    else:
+        f, v, occ = make_case(76, 16, 12, 3, flow="smooth", flow_scale=1.5)
+        rng = np.random.default_rng(1)
+        kw = {"u0_frame": rng.random((64, 48)), "w0_frame": 0.1 * rng.random((64, 48))}
+    P = orc.build_problem(f, v, factor=factor, kappa=0.25, flowDirection="backward", k=k, interpMethod=sampling, **kw)
+    s = make_solver(P, f, v, None, 0.25, "backward", factor=factor, k=k, sampling=sampling)
+    if kw:
+        s.set_fixed_frame(kw["u0_frame"], kw["w0_frame"])
+    s.init()
+    s.set_diagnostics(_capi.DIAG_ALWAYS)
+    st = s.solve(40, 0.0, 0)
+    x, y, _ = orc.pdhg(P, 40)
+    assert_stats_close(st, oracle_stats(P, x, y), scale=2.0)
+    s.close()
+
+
+def test_group_diagnostics_equal_the_single_block():
+    from superresolution_amd import _capi
+    from superresolution_amd.solver import SequenceGroupSolver
+    f, v, occ = make_case(77, 16, 12, 7, flow="smooth", flow_scale=2.0, with_occ=True)
+    P = orc.build_problem(f, v, kappa=0.25, flowDirection="forward-backward", k=KBLUR, occ=occ)
+    s = make_solver(P, f, v, occ, 0.25, "forward-backward")
+    s.init()
+    s.set_diagnostics(_capi.DIAG_ALWAYS)
+    st1 = s.solve(50, 0.0, 25)
+    h = s.h
+    s.close()
+    with SequenceGroupSolver(16, 12, 4, 7, nblocks=3, kappa=0.25, h=h, flow_direction="forward-backward") as g:
+        g.set_lowres(f); g.set_blur(KBLUR); g.set_flow(v, occ); g.set_state(P.u_up, P.u_up); g.init()
+        g.set_diagnostics(_capi.DIAG_ALWAYS)
+        seen = []
+        stg = g.solve(50, 0.0, 25, callback=lambda it, d: seen.append(it) and False)
+    assert seen == [25, 50]
+    for key in ("primal_energy", "dual_energy", "gap", "dual_infeasibility", "opt_res_primal", "opt_res_dual", "norm_KTy", "norm_Kx"):
+        assert abs(stg[key] - st1[key]) <= 1e-6 * abs(st1[key]) + 1e-9 * abs(st1["primal_energy"]), key
+
+
+def test_tolerance_stop_is_the_residual_test():
+    """With a tolerance the solve stops on the absolute + relative optimality residuals (the test the
+    reference asks of prost with all four tolerances = tol_pd, MultiframeMotionCoupling.m:357-363);
+    with the diagnostics off it stops on the relative change of the iterates."""
+    from superresolution_amd import _capi
+    f, v, _ = make_case(5, 12, 12, 3)
+    P = orc.build_problem(f, v, k=KBLUR)
+    s = make_solver(P, f, v, None, 0.25, "backward")
+    s.init()
+    tol = 1e-4
+    st = s.solve(6000, tol, 50)
+    n_primal, n_dual = s.problem_size()
+    assert (n_primal, n_dual) == (2.0 * P.M, float(P.K.shape[0]))
+    assert st["converged"] and st["iterations"] < 6000 and st["iterations"] % 50 == 0
+    assert st["opt_res_primal"] <= tol * np.sqrt(n_primal) + tol * st["norm_KTy"]
+    assert st["opt_res_dual"] <= tol * np.sqrt(n_dual) + tol * st["norm_Kx"]
+    # the oracle's residuals at that iteration pass the same test (within float32)
+    x, y, _ = orc.pdhg(P, st["iterations"])
+    rp, rd, nkty, nkx = orc.optimality_residuals(P, x, y)
+    assert rp <= 1.05 * (tol * np.sqrt(n_primal) + tol * nkty) and rd <= 1.05 * (tol * np.sqrt(n_dual) + tol * nkx)
+    # ... and one check earlier they did not
+    x, y, _ = orc.pdhg(P, st["iterations"] - 50)
+    rp, rd, nkty, nkx = orc.optimality_residuals(P, x, y)
+    assert rp > 0.95 * (tol * np.sqrt(n_primal) + tol * nkty) or rd > 0.95 * (tol * np.sqrt(n_dual) + tol * nkx)
+    s.close()
+    s = make_solver(P, f, v, None, 0.25, "backward")
+    s.init()
+    s.set_diagnostics(_capi.DIAG_OFF)
+    st = s.solve(6000, tol, 50)
+    assert st["converged"] and max(st["res_primal"], st["res_dual"]) < tol and np.isnan(st["gap"])
+    s.close()

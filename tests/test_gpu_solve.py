@@ -63,6 +63,8 @@ def test_energy_decreases_and_tolerance_stop():
     P = orc.build_problem(f, v, k=KBLUR)
     s = FrameBlockSolver(12, 12, 4, 3)
     s.set_lowres(f); s.set_blur(KBLUR); s.set_flow(v); s.set_state(P.u_up, P.u_up); s.init()
+    from superresolution_amd import _capi
+    s.set_diagnostics(_capi.DIAG_OFF)        # stop on the relative change of the iterates (the residual test: test_gpu_diagnostics.py)
     e0 = s.energy()
     seen = []
     st = s.solve(4000, 1e-4, 50, callback=lambda it, d: seen.append((it, d["res_primal"])) and False)

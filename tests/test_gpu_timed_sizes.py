@@ -1,0 +1,93 @@
+"""Correctness at the sizes bench.py times and BASELINE.json names, not only at small cuts of them:
+
+  config 3  30 frames of 1080x1920 in one block (the bench line's workload): the iterate after 20
+            iterations against the C restatement (oracle/mmc_oracle_c.c) on the same inputs, <= 1e-4
+  config 4  240 frames of 1080x1920 as one sequence on this GPU (26 GB of planes), cut into 8 and into
+            4 frame blocks: both cuts give the same bits, every value is finite and inside the box,
+            the energy and the optimality residuals fall, the gap shrinks
+  config 5  120 frames of 2160x3840 (52 GB), the same properties with 8 and 3 blocks
+
+The long sequences are too large for the CPU oracle to finish in seconds; their checks are the
+size-independent ones.  Frames and flows repeat with period 8 (rendering hundreds of distinct
+frames on the host would take minutes and test nothing more)."""
+import numpy as np
+import pytest
+
+import mmc_oracle as orc
+import mmc_oracle_c as occ
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+KBLUR = orc.fspecial_gaussian(7, np.sqrt(0.6))
+
+
+def test_config3_thirty_frames_of_1080p_against_the_c_restatement():
+    if not occ.available():
+        pytest.skip("C oracle not built")
+    from superresolution_amd import synthetic
+    from superresolution_amd.solver import FrameBlockSolver
+    ny, nx, nc, iters = 270, 480, 30, 20
+    blk = synthetic.make_block(ny, nx, nc, 0, nc, device="cpu")
+    u_up = np.stack([orc.imresize(blk["f"][:, :, i].astype(np.float64), 4) for i in range(nc)], axis=2).astype(np.float32)
+    with FrameBlockSolver(ny, nx, 4, nc) as s:
+        s.set_lowres(blk["f"]); s.set_blur(KBLUR); s.set_flow(blk["v"]); s.set_state(u_up, u_up); s.init()
+        st = s.solve(iters, 0.0, 0)
+        u, w = s.get_state()
+        h = s.h
+        d = s.diagnostics()
+    u_ref, w_ref, info = occ.solve(blk["f"], blk["v"], u_up, u_up, iters, k=KBLUR, h=h)
+    assert st["iterations"] == iters
+    assert rel_l2(u, u_ref) <= 1e-4 and np.abs(u - u_ref).max() <= 1e-4 and np.abs(w - w_ref).max() <= 1e-4
+    assert abs(d["primal_energy"] - info["primal_energy"]) <= 1e-4 * info["primal_energy"]
+    assert abs(d["gap"] - info["gap"]) <= 1e-3 * abs(info["gap"]) + 2e-4 * info["primal_energy"]
+
+
+def _long_sequence(ny, nx, nc, period=8):
+    from superresolution_amd import synthetic
+    blk = synthetic.make_block(ny, nx, period + 1, 0, period + 1, device="cpu")
+    idx = np.arange(nc) % period
+    f = np.ascontiguousarray(blk["f"][:, :, idx], dtype=np.float32)
+    v = np.asarray(blk["v"]).reshape(4 * ny, 4 * nx, period, 2, order="F")[:, :, np.arange(nc - 1) % period, :]
+    return np.asfortranarray(f), np.asfortranarray(v, dtype=np.float32)
+
+
+def _group_run(f, v, nblocks, iters, h):
+    from superresolution_amd import _capi
+    from superresolution_amd.solver import SequenceGroupSolver
+    ny, nx, nc = f.shape
+    seen = []
+    with SequenceGroupSolver(ny, nx, 4, nc, nblocks=nblocks, h=h) as g:
+        g.set_lowres(f); g.set_blur(KBLUR); g.set_flow(v)
+        g.set_state()                                   # bicubic start point, computed on the device
+        g.init()
+        hh = g.h
+        g.set_diagnostics(_capi.DIAG_ALWAYS)
+        st = g.solve(iters, 0.0, max(iters // 3, 1), callback=lambda it, d: seen.append(dict(d)) and False)
+        u, w = g.get_state()
+    return u, w, hh, st, seen
+
+
+def _check_long(ny, nx, nc, cuts, iters):
+    f, v = _long_sequence(ny, nx, nc)
+    u1, w1, h, st, seen = _group_run(f, v, cuts[0], iters, 0.0)
+    assert st["iterations"] == iters and len(seen) >= 3
+    assert np.isfinite(u1).all() and np.isfinite(w1).all() and u1.min() >= 0.0 and u1.max() <= 1.0
+    e = [d["primal_energy"] for d in seen]
+    g = [d["gap"] for d in seen]
+    r = [d["opt_res_primal"] + d["opt_res_dual"] for d in seen]
+    assert all(a > b for a, b in zip(e, e[1:])) and all(a > b for a, b in zip(g, g[1:])) and all(a > b for a, b in zip(r, r[1:]))
+    assert all(d["res_primal"] > 0 and np.isfinite(d["res_primal"]) for d in seen)
+    # a frame in the middle of the sequence differs from its start point, frames with equal inputs far from
+    # the ends of the sequence agree closely (period 8), the ends do not (they lack a neighbour)
+    assert np.abs(u1[:, :, nc // 2] - u1[:, :, nc // 2 + 8]).max() < 1e-3
+    u2, w2, h2, st2, seen2 = _group_run(f, v, cuts[1], iters, h)
+    assert np.array_equal(u1, u2) and np.array_equal(w1, w2)
+    assert abs(seen2[-1]["gap"] - seen[-1]["gap"]) <= 1e-6 * abs(seen[-1]["primal_energy"])
+
+
+def test_config4_240_frames_of_1080p_as_frame_blocks_on_one_gpu():
+    _check_long(270, 480, 240, (8, 4), 9)
+
+
+def test_config5_120_frames_of_4k_as_frame_blocks_on_one_gpu():
+    _check_long(540, 960, 120, (8, 3), 6)

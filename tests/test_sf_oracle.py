@@ -63,3 +63,29 @@ def test_one_frame_zero_flow_is_tv_deblurring_of_that_frame():
     x, _, _ = sfo.pdhg(P, 1500)
     r = P.K[:P.n] @ x - P.f
     assert np.abs(r).mean() < 0.01
+
+
+def test_huber_parameter_also_smooths_the_regulariser():
+    """singleframeMotionSR_unger_prost.m:163 passes huber_eps/alpha as the quadratic coefficient of the
+    gradient dual: q <- proj_alpha(q~ / (1 + s delta/alpha)), the conjugate of alpha * Huber_delta(|grad u|)."""
+    f, v, _ = make_sf_case(9, 6, 6, 3, flow_scale=1.0)
+    P = sfo.build_problem(f, v, alpha=0.1, huber_eps=0.05, k=K7)
+    m = P.n * P.nf
+    rng = np.random.default_rng(0)
+    y = rng.normal(0, 0.2, P.K.shape[0])
+    S = rng.random(P.K.shape[0]) + 0.1
+    S[m:] = np.tile(S[m:m + P.N], 2)
+    out = sfo.prox_Fstar(P, y, S)
+    # brute force per group: argmin_q  |q - y|^2 / (2 s) + (delta/alpha)/2 |q|^2  s.t. |q| <= alpha
+    q = y[m:].reshape(2, P.N) / (1.0 + S[m:m + P.N] * 0.05 / 0.1)
+    nrm = np.sqrt((q * q).sum(axis=0))
+    q = q * np.minimum(1.0, 0.1 / np.maximum(nrm, 1e-300))
+    assert np.allclose(out[m:].reshape(2, P.N), q, atol=1e-14)
+    # it changes the solution, and the energy it decreases is the Huber-TV one
+    x_h, _, _ = sfo.pdhg(P, 300)
+    P0 = sfo.build_problem(f, v, alpha=0.1, huber_eps=0.0, k=K7)
+    x_0, _, _ = sfo.pdhg(P0, 300)
+    assert np.abs(x_h - x_0).max() > 1e-3
+    assert sfo.primal_energy(P, x_h) < sfo.primal_energy(P, x_0) + 1e-12
+    g = (P.K @ x_h)[m:].reshape(2, P.N)
+    assert sfo.primal_energy(P, x_h) < sfo.primal_energy(P0, x_h)        # Huber <= absolute value, term by term
