@@ -253,7 +253,9 @@ int mmc_get_h(const mmc_handle *h, float *value);
  *        component masks the row (fold an occlusion map in beforehand); may be NULL when nc == 1
  *   d_out 2 doubles          device: [0] = sum |W u|, [1] = sum |grad u|
  * Both kernels are queued on `stream` (a hipStream_t, NULL = the default stream) of `device`;
- * the call does not synchronise, d_out is valid once the stream has passed it.  The per-workgroup
+ * the call does not synchronise, d_out is valid once the stream has passed it.  The caller's
+ * current device is the same after the call as before it.  The first call on a device looks the
+ * workspace's address up (hipGetSymbolAddress); make that call outside a stream capture.  The per-workgroup
  * partial sums live in a static device array of 8 MiB that each GPU used holds until the process
  * ends: ceil(Ny*Nx/256)*nc must not exceed MMC_STATIC_MAX_BLOCKS (30 frames of 1080p need
  * 243000, 15 frames of 2160x3840 need 486000); larger inputs are rejected with

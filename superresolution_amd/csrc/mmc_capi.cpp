@@ -194,13 +194,18 @@ extern "C" const char *mmc_last_error(const mmc_handle *h) {
 static std::mutex g_skew_mutex;
 static std::map<std::array<int, 4>, size_t> g_skew_cache;     // (Ny, Nx, probed frames, device) -> chosen shift
 
+// Blocks of at least 64 MiB per plane whose frames take the row-quad sweeps are probed.
+static bool plane_is_probed(const mmc_handle *h) {
+    const size_t plane_bytes = frame_slots(h) * (size_t)h->g.N * sizeof(float);
+    return plane_bytes >= ((size_t)64 << 20) && h->g.Ny % 4 == 0;
+}
+
 static_assert(((size_t)64 << 10) + PLANE_SKEW_DEFAULT_STEP * ((size_t)32 << 10) == PLANE_SKEW_DEFAULT, "default shift must be a probe candidate");
 static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, size_t *skew) {
     const Geom &g = h->g;
     // tuning override: MMC_PLANE_SKEW=<bytes> fixes the shift, MMC_PROBE_TRACE=1 prints the probe's timings
     if (const char *e = getenv("MMC_PLANE_SKEW")) { *skew = std::min((size_t)atol(e) & ~(size_t)255, (size_t)PLANE_SKEW_MAX); return MMC_OK; }
-    const size_t plane_bytes = frame_slots(h) * (size_t)g.N * sizeof(float);
-    if (plane_bytes < ((size_t)64 << 20) || g.Ny % 4 != 0 || raw.size() < 12) return MMC_OK;
+    if (!plane_is_probed(h) || raw.size() < 12) return MMC_OK;
     // one probe per frame size and device in a process: the blocks of a group share its result
     const int nprobe = std::min(h->L, (int)PLANE_PROBE_FRAMES);
     const std::array<int, 4> key = {g.Ny, g.Nx, nprobe, h->prm.device};
@@ -367,17 +372,26 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     float **per_px[] = {&a.u, &a.w, &a.ub, &a.wb, &a.g1t, &a.g1x, &a.g1y, &a.g2t, &a.g2x, &a.g2y, &a.vx, &a.vy, &a.cW};
     int rc;
     {
-        // every plane gets room for the largest shift; the shifts are chosen below
-        const size_t room = (PLANE_SLOTS - 1) * PLANE_SKEW_MAX / sizeof(float);
+        // Every plane gets room for the largest shift it can end up with: the fixed one (default or
+        // MMC_PLANE_SKEW) when the block is not probed, the largest probe candidate otherwise.  Only the
+        // frames themselves are zeroed.
+        const size_t nplanes = sizeof(per_px) / sizeof(per_px[0]);
+        size_t max_skew = PLANE_SKEW_DEFAULT;
+        if (const char *e = getenv("MMC_PLANE_SKEW")) max_skew = std::min((size_t)atol(e) & ~(size_t)255, (size_t)PLANE_SKEW_MAX);
+        else if (plane_is_probed(h)) max_skew = ((size_t)64 << 10) + (size_t)(PLANE_SKEW_STEPS - 1) * ((size_t)32 << 10);
+        const size_t room = (nplanes - 1) * max_skew / sizeof(float);
         std::vector<float *> raw;
         for (float **pp : per_px) {
-            if ((rc = dev_alloc(h, pp, fs + room)) != MMC_OK) return bail(rc);
+            if ((rc = dev_alloc(h, pp, fs + room, false)) != MMC_OK) return bail(rc);
             raw.push_back(*pp);
         }
         size_t skew = PLANE_SKEW_DEFAULT;
         if ((rc = choose_plane_skew(h, raw, &skew)) != MMC_OK) return bail(rc);
         h->plane_skew = skew;
-        for (size_t i = 0; i < raw.size(); ++i) *per_px[i] = raw[i] + i * skew / sizeof(float);
+        for (size_t i = 0; i < raw.size(); ++i) {
+            *per_px[i] = raw[i] + i * skew / sizeof(float);
+            if (hipMemsetAsync(*per_px[i], 0, fs * sizeof(float), h->stream) != hipSuccess) { h->err = "hipMemsetAsync failed"; return bail(MMC_ERR_HIP); }
+        }
     }
     if ((rc = dev_alloc(h, &a.idq, (size_t)h->L * ((size_t)g.N / 4 + 1), true, 13 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.p, (size_t)h->L * g.n, true, 14 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);

@@ -1799,7 +1799,18 @@ extern "C" int mmc_h_partials_static(const float *d_u, const float *d_v, int Ny,
         return mmc_static_fail(MMC_ERR_INVALID_ARG,
                                "mmc_h_partials_static: sequence exceeds the static workspace "
                                "(ceil(Ny*Nx/256)*nc must not exceed MMC_STATIC_MAX_BLOCKS = 524288); use mmc_h_partials on a handle");
-    if (hipSetDevice(device) != hipSuccess) return mmc_static_fail(MMC_ERR_HIP, "mmc_h_partials_static: hipSetDevice failed");
+    // The caller's current device is put back before the call returns (DeviceGuard below).
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return mmc_static_fail(MMC_ERR_HIP, "mmc_h_partials_static: hipGetDevice failed");
+    if (cur != device) {
+        if (hipSetDevice(device) != hipSuccess) return mmc_static_fail(MMC_ERR_HIP, "mmc_h_partials_static: hipSetDevice failed");
+        guard.prev = cur;
+    }
+    (void)hipGetLastError();      // an error left behind by an unrelated earlier call must not be reported as ours
     double *part = nullptr;
     if (static_scratch_ptr(device, &part) != hipSuccess)
         return mmc_static_fail(MMC_ERR_HIP, "mmc_h_partials_static: hipGetSymbolAddress failed");

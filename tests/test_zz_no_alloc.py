@@ -4,7 +4,10 @@ GPU, the second with a smaller sequence: the static workspace keeps the first ca
 sums, and the second result must not see them.  The two entry points add the same float32
 workgroup sums, one with double atomics in arrival order and one in a fixed order, so they agree
 to the rounding of double additions (1e-12 relative is the bar written here); the static one is
-bitwise reproducible, which is checked as well."""
+bitwise reproducible, which is checked as well.  Both are also held against the sums of the explicit
+sparse restatement (oracle/mmc_oracle.py), and the contract itself is pinned: free device memory
+is the same before and after a call, the call can be recorded into a HIP graph (stream capture
+rejects allocations) and replayed, and the caller's current device is left alone."""
 import ctypes as C
 
 import numpy as np
@@ -58,6 +61,49 @@ def test_static_entry_point_matches_handle_twice(direction):
         for a, b in zip(got, ref):
             assert abs(a - b) <= 1e-12 * abs(b), (got, ref)
         assert got == again                   # fixed summation order
+        # the same two sums from the explicit sparse matrices (MultiframeMotionCoupling.m:431-437), float64
+        import mmc_oracle as orc
+        P = orc.build_problem(f, v, occ=occ, flowDirection=direction)
+        uu = P.u_up.ravel(order="F")
+        for a, b in zip(got, (np.abs(P.W @ uu).sum(), np.abs(P.G @ uu).sum())):
+            assert abs(a - b) <= 2e-5 * abs(b), (got, b)
+
+
+def test_static_entry_point_allocates_nothing_and_can_be_captured():
+    """Free device memory is unchanged by a call, the call records into a HIP graph (capture fails on
+    any allocation or synchronisation inside it) and the replayed graph gives the same two sums."""
+    import torch
+    from superresolution_amd import _capi
+    lib = _capi.load_library()
+    f, v, occ = make_case(9, 16, 20, 3, flow="smooth", flow_scale=2.0, with_occ=False)
+    u_up, ref = _handle_sums(f, v, occ, "backward")
+    first = _static_sums(u_up, v, occ, "backward")         # pays the one-off symbol lookup on this device
+    Ny, Nx, nc = u_up.shape
+    d_u = torch.from_numpy(np.ravel(np.asfortranarray(u_up, dtype=np.float32), order="F").copy()).cuda()
+    d_v = torch.from_numpy(np.ravel(np.asfortranarray(v, dtype=np.float32), order="F").copy()).cuda()
+    d_out = torch.full((2,), -1.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    assert lib.mmc_h_partials_static(d_u.data_ptr(), d_v.data_ptr(), Ny, Nx, nc, 1, 0, None, d_out.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert tuple(d_out.cpu().numpy().tolist()) == first
+    # under stream capture
+    d_out.fill_(-1.0)
+    s = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=s, capture_error_mode="global"):
+        rc = lib.mmc_h_partials_static(d_u.data_ptr(), d_v.data_ptr(), Ny, Nx, nc, 1, 0,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream), d_out.data_ptr())
+    assert rc == 0, lib.mmc_last_error(None).decode()
+    torch.cuda.synchronize()
+    assert tuple(d_out.cpu().numpy().tolist()) == (-1.0, -1.0)      # recorded, not run
+    graph.replay()
+    torch.cuda.synchronize()
+    assert tuple(d_out.cpu().numpy().tolist()) == first
+    for a, b in zip(first, ref):
+        assert abs(a - b) <= 1e-12 * abs(b)
 
 
 def test_static_entry_point_rejects_what_does_not_fit():
