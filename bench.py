@@ -73,6 +73,11 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional rehearsal: ranks share the visible GPUs (use with --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-group-leg", action="store_true",
+                    help="N > 1: skip the extra leg that times the same sequence through mmc_group_* (one process, one "
+                         "host thread driving all N devices: what the MEX gateway calls)")
+    ap.add_argument("--group-blocks", type=int, default=0,
+                    help="N = 1: also time the sequence cut into this many frame blocks on the one GPU through mmc_group_*")
     return ap.parse_args()
 
 
@@ -207,6 +212,31 @@ def parity_check(s, keep, model):
         res["max_abs_w"] = float(np.abs(w.astype(np.float64) - keep["w"]).max())
     res["ok"] = bool(res["rel_l2_u"] <= 1e-4)
     return res
+
+
+def group_leg(args, ny, nx, nc, devices, in_dev):
+    """The same sequence through mmc_group_* (one process, one host thread, one frame block per entry
+    of `devices`; MultiframeMotionCoupling.m:977-986 is one call from one MATLAB session): warm-up,
+    then args.steps iterations timed between two device synchronisations."""
+    from superresolution_amd import synthetic
+    from superresolution_amd.solver import SequenceGroupSolver
+    blk = synthetic.make_block(ny, nx, nc, 0, nc, factor=4, device=in_dev, flow_kind=args.flow)
+    with SequenceGroupSolver(ny, nx, 4, nc, nblocks=len(devices), devices=devices, alpha=0.01, kappa=args.kappa, h=0.0,
+                             flow_direction=args.direction, sampling="average", device=devices[0]) as g:
+        g.set_lowres(blk["f"])
+        g.set_blur(synthetic.gaussian_kernel())
+        g.set_flow(blk["v"])
+        del blk
+        g.set_state()               # bicubic start point, computed on the devices
+        g.init()
+        g.solve(args.warmup, 0.0, 0)
+        t0 = time.perf_counter()
+        st = g.solve(args.steps, 0.0, 0)      # returns device-synchronised
+        wall = time.perf_counter() - t0
+        assert st["iterations"] == args.steps
+    M = 16 * ny * nx * nc
+    return {"driver": "mmc_group_* (one process, one host thread)", "devices": list(devices), "frames_total": nc,
+            "ms_per_step": wall / args.steps * 1e3, "value": M * args.steps / wall / 1e6}
 
 
 def measured_traffic(kernel, model, L, Ny, Nx):
@@ -378,6 +408,28 @@ def main():
                     "iterations": int(min(it_p, it_d))}
     assert st["iterations"] == args.steps
 
+    # Extra leg (never the headline): the one-process driver on the same devices, from rank 0 while
+    # the other ranks wait; at N = 1 only on request, as several blocks on the one GPU.
+    group = None
+    group_devices = None
+    if world > 1 and not args.no_group_leg:
+        group_devices = [r % torch.cuda.device_count() for r in range(world)] if args.share_gpu else list(range(world))
+    elif world == 1 and args.group_blocks > 1:
+        group_devices = [local_rank] * args.group_blocks
+    if group_devices is not None:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            log("group leg on devices %s" % group_devices)
+            try:
+                group = group_leg(args, ny, nx, nc, group_devices, in_dev)
+                group["vs_headline"] = group["value"] / (M_total * args.steps / wall / 1e6)
+            except Exception as e:      # the headline stands on its own
+                group = {"error": repr(e)}
+            torch.cuda.set_device(local_rank)
+        if dist is not None:
+            dist.barrier()
+
     if rank == 0:
         value = M_total * args.steps / wall / 1e6
         out = {
@@ -403,6 +455,8 @@ def main():
         }
         if extra:
             out["other_flows"] = extra
+        if group is not None:
+            out["group_driver"] = group
         if prof is not None and prof["iterations"] > 0:
             # the dual sweep is one fused kernel (k_dual4); its second slot only times the event gap
             kernels = {"k_primal4": (prof["primal_ms"], BYTES_PRIMAL[model]),

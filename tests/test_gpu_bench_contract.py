@@ -48,6 +48,9 @@ def test_single_gpu_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == d["unit"] and cb["sample"]
     assert d["sustained"]["steps"] >= 200 and d["sustained"]["value"] > 0
+    assert "group_driver" not in d
+    g = run_bench(["--no-cpu-baseline", "--group-blocks", "3"])
+    assert g["group_driver"]["devices"] == [0, 0, 0] and g["group_driver"]["value"] > 0
 
 
 def test_two_ranks_started_by_the_command_itself():
@@ -55,5 +58,10 @@ def test_two_ranks_started_by_the_command_itself():
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["backend"] == "gloo"
     assert d["config"]["frames_total"] == 6 and d["scaling"] == "weak"
     assert d["value"] > 0 and "cpu_baseline" not in d
+    # extra leg: the same six frames through the one-process driver, one block per rank's device
+    gd = d["group_driver"]
+    assert "error" not in gd, gd
+    assert gd["devices"] == [0, 0] and gd["frames_total"] == 6 and gd["value"] > 0
+    assert math.isclose(gd["value"], 4 * 64 * 4 * 96 * 6 / gd["ms_per_step"] / 1e3, rel_tol=1e-9)
     s = run_bench(["--gpus", "2", "--share-gpu", "--backend", "gloo", "--no-cpu-baseline", "--total-frames", "5"])
     assert s["scaling"] == "strong" and s["config"]["frames_total"] == 5
