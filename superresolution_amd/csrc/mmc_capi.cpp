@@ -42,6 +42,7 @@ struct mmc_handle {
     size_t ovf_capacity = 0;                 // entries allocated for a.ovf_idx
     size_t ovf_total = 0;                    // entries in use
     std::string err;
+    bool geometry_only = false;              // no per-pixel state (mmc_internal_create_geometry)
     size_t plane_skew = 0;                   // bytes between the starts of consecutive per-pixel planes modulo their allocation alignment
     int diagnostics = MMC_DIAG_AUTO;         // when the second group of mmc_stats is evaluated
     bool profiling = false;
@@ -273,7 +274,9 @@ static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, siz
 
 extern "C" size_t mmc_debug_plane_skew(const mmc_handle *h) { return h ? h->plane_skew : 0; }
 
-extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
+// geometry_only: the handle carries the geometry and the data operator D*B (composite kernel, its row
+// and column sums) and none of the per-pixel state; the single-frame solve owns such a handle.
+static int create_handle(const mmc_params *p, bool geometry_only, mmc_handle **out) {
     if (!p || !out) return fail(nullptr, MMC_ERR_INVALID_ARG, "mmc_create: null argument");
     *out = nullptr;
     if (p->size != sizeof(mmc_params) || p->version != MMC_ABI_VERSION)
@@ -371,6 +374,18 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     const size_t fs = frame_slots(h) * (size_t)g.N;
     float **per_px[] = {&a.u, &a.w, &a.ub, &a.wb, &a.g1t, &a.g1x, &a.g1y, &a.g2t, &a.g2x, &a.g2y, &a.vx, &a.vy, &a.cW};
     int rc;
+    h->geometry_only = geometry_only;
+    if (geometry_only) {
+        if ((rc = dev_alloc(h, &a.cA, (size_t)g.N)) != MMC_OK) return bail(rc);
+        if ((rc = dev_alloc(h, &a.sigp, (size_t)g.n)) != MMC_OK) return bail(rc);
+        if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
+        if ((rc = dev_alloc(h, &a.ckq, (size_t)(MMC_MAX_CK + 8) * MMC_MAX_CK)) != MMC_OK) return bail(rc);
+        if ((rc = dev_alloc(h, &a.ckp, (size_t)(MMC_MAX_CK + p->factor) * (MMC_MAX_CK + p->factor))) != MMC_OK) return bail(rc);
+        if ((rc = dev_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)) != MMC_OK) return bail(rc);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MMC_ERR_HIP); }
+        *out = h;
+        return MMC_OK;
+    }
     {
         // Every plane gets room for the largest shift it can end up with: the fixed one (default or
         // MMC_PLANE_SKEW) when the block is not probed, the largest probe candidate otherwise.  Only the
@@ -413,6 +428,9 @@ extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) {
     *out = h;
     return MMC_OK;
 }
+
+extern "C" int mmc_create(const mmc_params *p, mmc_handle **out) { return create_handle(p, false, out); }
+int mmc_internal_create_geometry(const mmc_params *p, mmc_handle **out) { return create_handle(p, true, out); }
 
 extern "C" int mmc_destroy(mmc_handle *h) {
     if (!h) return MMC_OK;

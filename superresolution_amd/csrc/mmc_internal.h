@@ -214,4 +214,8 @@ hipStream_t mmc_internal_stream(const mmc_handle *h);
 const Geom *mmc_internal_geom(const mmc_handle *h);
 const Arrays *mmc_internal_arrays(const mmc_handle *h);
 int mmc_internal_build_data_operator(mmc_handle *h);
+// A handle with the geometry and the data operator of a one-frame block and none of the per-pixel
+// state (validates the parameters as mmc_create does); only mmc_set_blur, mmc_internal_* and
+// mmc_destroy may be called on it.
+int mmc_internal_create_geometry(const struct mmc_params *p, mmc_handle **out);
 int mmc_internal_set_flow_planes(mmc_handle *h, const float *vcol, const float *vrow, const uint8_t *occ);

@@ -91,7 +91,7 @@ extern "C" int mmc_sf_create(const mmc_sf_params *p, mmc_sf_handle **out) {
     gp.flow_direction = MMC_FLOW_BACKWARD; gp.sampling = p->sampling;
     gp.device = p->device; gp.stream = p->stream;
     mmc_handle *geo = nullptr;
-    int rc = mmc_create(&gp, &geo);
+    int rc = mmc_internal_create_geometry(&gp, &geo);
     if (rc != MMC_OK) return sfail(nullptr, rc, mmc_last_error(nullptr));
     mmc_sf_handle *h = new mmc_sf_handle();
     h->prm = *p;
