@@ -759,8 +759,15 @@ static int build_data_operator(mmc_handle *h) {
         for (int mm = 0; mm < g.CH; ++mm) ckpad[(size_t)mm + (size_t)g.MP * nn] = ckf[(size_t)mm + (size_t)g.CH * nn];
     HIPCHK(h, hipMemcpyAsync(h->a.ckp, ckpad.data(), ckpad.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     g.wpad = (4 - ((-g.oy) & 3)) & 3;
-    g.SRp = (g.wpad + TILE_R + g.CH - g.f + 3) & ~3;
     g.MPq = (g.wpad + g.CH + 3) & ~3;
+    {
+        // Window height: the rows the tile's low-res pixels touch (with a zoom factor that does not divide the
+        // tile they reach up to f - 1 rows further), and room for whole rows of the padded kernel table from
+        // the last low-res pixel's first row on (the even-zoom path reads them in pairs; the padding is zero).
+        const int fe = (TILE_R % g.f == 0 && TILE_C % g.f == 0) ? g.f : 1;
+        const int rows = std::max(g.wpad + TILE_R + g.CH - fe, TILE_R - fe + g.MPq);
+        g.SRp = (rows + 3) & ~3;
+    }
     std::vector<float> ckq((size_t)g.MPq * g.CW, 0.f);
     for (int nn = 0; nn < g.CW; ++nn)
         for (int mm = 0; mm < g.CH; ++mm) ckq[(size_t)(g.wpad + mm) + (size_t)g.MPq * nn] = ckf[(size_t)mm + (size_t)g.CH * nn];

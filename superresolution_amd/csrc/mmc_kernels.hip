@@ -210,6 +210,12 @@ __device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
 #ifndef MMC_OCC_PRIMAL
 #define MMC_OCC_PRIMAL 1
 #endif
+#ifndef MMC_PRIMAL_EARLY_X
+#define MMC_PRIMAL_EARLY_X 0    // 1: the primal sweep loads u, w and the step-size inputs ahead of the scatter (one round trip less per workgroup)
+#endif
+#ifndef MMC_SCATTER_SCU
+#define MMC_SCATTER_SCU 5       // source pixels per thread and pass of the primal sweep's scatter
+#endif
 #ifndef MMC_OCC_DUAL
 #define MMC_OCC_DUAL 1
 #endif
@@ -257,6 +263,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
     float gx1[4], gl1[4] = {0.f, 0.f, 0.f, 0.f}, gy1[4], up1 = 0.f;
     float gx2[4], gl2[4] = {0.f, 0.f, 0.f, 0.f}, gy2[4], up2 = 0.f;
     float sA1[4] = {0.f, 0.f, 0.f, 0.f}, sA2[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned idb = 0;             // identity bits of this quad (CWS)
     // Loads of this thread's own quad, in groups.  The dual planes (grp1, grp2, grpA) are issued
     // here, ahead of the scatter, and are folded into eu / ew right after the staging barrier; the
     // state and step-size planes (grpX) are issued after the scatter, where they are first needed
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
         if (grpX && MODE == MODE_DUALOBJ) ld4(uo, FR(a.u, t) + j);      // no step sizes in this mode
         if (grpX && MODE != MODE_DUALOBJ) {
             if (!CWS) ld4(cWv, FR(a.cW, t) + j);
+            else idb = a.idq[(size_t)t * (g.N / 4 + 1) + (j >> 2)];
             if (F == 4 && g.cA_margin > 0 && r >= g.cA_margin && r + 4 <= g.Ny - g.cA_margin &&
                 c >= g.cA_margin && c < g.Nx - g.cA_margin && !ABL(128)) {
                 // interior: period-4 pattern (row phase of quad row i is i)
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
             if (MODEL == MODEL_IC) ld4(sA2, FR(a.g2t, t) + j);
         }
     };
-    own_loads(false, true, true, true);
+    own_loads(MMC_PRIMAL_EARLY_X != 0, true, true, true);
 
     // source boxes of the scatter below, fetched ahead of the barrier
     int4 sbox[2] = {make_int4(0, -1, 0, -1), make_int4(0, -1, 0, -1)};
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
     // SCU source pixels per thread and pass, all their loads issued before the
     // first use so that one pass costs one memory round trip.
     if (MODE != MODE_STEPS) {
-        constexpr int SCU = 5;
+        constexpr int SCU = MMC_SCATTER_SCU;
         for (int which = 0; which < 2; ++which) {
             const int q = which == 0 ? t - 1 : t;
             if (!pair_exists(g, q)) continue;
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
         __syncthreads();
     }
 
-    own_loads(true, false, false, false);      // u, w, cW, cA: only needed from here on
+    if (!MMC_PRIMAL_EARLY_X) own_loads(true, false, false, false);      // u, w, cW, cA: only needed from here on
     float part[2] = {0.f, 0.f};
     float dob[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
@@ -428,7 +436,6 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
         const bool isfix = MODEL == MODEL_IC && g.fixed && g.frame_begin + t == 0;   // identity rows of q1, q2 (:560-561)
         const float fixc = isfix ? 1.f : 0.f;
         if (CWS) {
-            const unsigned idb = a.idq[(size_t)t * (g.N / 4 + 1) + (j >> 2)];
 #pragma unroll
             for (int i = 0; i < 4; ++i) cWv[i] = from_fx(acc3[4 * rq + i + TILE_R * lc]) + (float)((idb >> (2 * i)) & 3u);
         }
@@ -796,12 +803,12 @@ __global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0
 // --------------------------------------------------------------------------
 // dual sweep, row-quad form with the data-term update fused in
 // --------------------------------------------------------------------------
-// Needs Ny % 4 == 0 and a zoom factor that divides the tile (whole low-res
-// pixels per tile).  Each thread owns four consecutive rows of one column for
+// Needs Ny % 4 == 0.  Each thread owns four consecutive rows of one column for
 // the regulariser duals.  The workgroup also stages xbar_u of its tile plus the
 // blur halo in LDS (replicate border applied while staging) and updates the
-// low-res dual p of the tile from it: wave w sums the composite-kernel columns
-// n = w, w+4, ... for every low-res pixel, the four partial sums meet in LDS.
+// low-res duals p it owns from it: those whose first high-res pixel (f R, f C)
+// lies in the tile.  Groups of adjacent lanes share a low-res pixel and split
+// the composite-kernel columns among them.
 template <int MODEL, int MODE, bool REDUCE, int F>
 __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
@@ -819,8 +826,11 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
     const bool isIF = pair_is_IF(g, t);
     // Zoom 4: the window starts on a row quad (g.wpad extra rows on top, height g.SRp), so that it
     // is staged with 16-byte loads and each low-res pixel reads its kernel rows as aligned float4.
-    const bool VEC = F == 4 && g.SRp <= 128 && !ABL(4096);
-    const int SR = VEC ? g.SRp : TILE_R + g.CH - f, SC = TILE_C + g.CW - f;
+    // The padded window (16-byte staging) serves every zoom factor that divides the tile; the
+    // lane-quad data term below is the zoom-4 form of it.
+    const bool VEC = g.SRp <= 128 && !ABL(4096);
+    const int fe = (TILE_R % f == 0 && TILE_C % f == 0) ? f : 1;      // 1: low-res blocks straddle tile borders
+    const int SR = VEC ? g.SRp : TILE_R + g.CH - fe, SC = TILE_C + g.CW - fe;
     const int wpad = VEC ? g.wpad : 0;
     const int LRR = TILE_R / f, LRC = TILE_C / f, nlr = LRR * LRC;
     constexpr int NWV = MMC_THREADS / 64;
@@ -859,7 +869,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
     // The data-term window of xbar_u also holds this quad's right neighbour column and the row below it
     // when the composite kernel reaches at least one pixel beyond the tile on those sides.
     const bool nb_lds = MMC_DUAL_UX_LDS && VEC && MODE != MODE_STEPS && g.oy <= 0 && g.ox <= 0 &&
-                        g.oy + g.CH - f - 1 >= 0 && g.ox + g.CW - f - 1 >= 0;
+                        g.oy + g.CH - fe - 1 >= 0 && g.ox + g.CW - fe - 1 >= 0;
     // own loads first; they stay in flight while the window is staged
     float o1t[4], o1x[4], o1y[4], o2t[4], o2x[4], o2y[4], fvx[4], fvy[4];
     float uc[4], ux[4], wc[4] = {0.f, 0.f, 0.f, 0.f}, wx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1105,7 +1115,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
     // kernel among them (lane part takes columns part, part+4, ...); two lane exchanges add the
     // four partial sums, lane 0 of the group updates p.  No second barrier, no partial sums in LDS;
     // the loads of p, f and the step size are in flight while the sums are formed.
-    const bool QUAD = MMC_DATA_QUAD && VEC && 4 * nlr == MMC_THREADS;
+    const bool QUAD = MMC_DATA_QUAD && F == 4 && VEC && 4 * nlr == MMC_THREADS;
     if (QUAD && MODE != MODE_STEPS && !ABL(512)) {
         const int lp = tid >> 2, part4 = tid & 3;
         const int Rl = lp % LRR, Cl = lp / LRR;
@@ -1144,12 +1154,82 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
             }
         }
     }
-    if (!QUAD && MODE != MODE_STEPS && !ABL(512)) {
+    // Every other zoom factor.  A low-res pixel belongs to the tile that holds the first high-res pixel
+    // of its block (f R, f C), so factors that do not divide the tile (zoom 3) work as well; the window
+    // then reaches f - 1 rows / columns further (g.SRp and SC allow for it).  LPP adjacent lanes share a
+    // low-res pixel (zoom 2: one lane each, zoom 8: 16 lanes), split the kernel columns among them and add
+    // their partial sums by lane exchanges, as the quads do.  Kernel weights come from the copy in LDS
+    // (broadcast reads): as loads from global memory inside these loops they cost a third of the sweep.
+    const int LRRm = (TILE_R + f - 1) / f, LRCm = (TILE_C + f - 1) / f;      // most low-res rows / columns a tile owns
+    int LPP = 1;
+    while (2 * LPP * LRRm * LRCm <= MMC_THREADS && LPP < 64) LPP *= 2;
+    const bool LANES = F != 4 && !QUAD && VEC;
+    if (LANES && !ABL(512)) {
+        const int LR0 = (r0 + f - 1) / f, LC0 = (c0 + f - 1) / f;              // first low-res row / column of this tile
+        const int LRRt = max(min((r0 + TILE_R + f - 1) / f, g.ny) - LR0, 0);
+        const int LRCt = max(min((c0 + TILE_C + f - 1) / f, g.nx) - LC0, 0);
+        const int nlrt = LRRt * LRCt;
+        const int sub = tid & (LPP - 1);
+        const float inv_lrr = fast_rcp((float)max(LRRt, 1));
+        for (int lp = tid / LPP; lp < nlrt; lp += MMC_THREADS / LPP) {
+            int Cl = (int)(((float)lp + 0.5f) * inv_lrr);
+            int Rl = lp - Cl * LRRt;
+            if (Rl < 0) { --Cl; Rl += LRRt; }
+            if (Rl >= LRRt) { ++Cl; Rl -= LRRt; }
+            const int R = LR0 + Rl, C = LC0 + Cl;
+            const int i = R + g.ny * C;
+            const size_t o = (size_t)t * g.n + i;
+            const bool owner = sub == 0;
+            if (MODE == MODE_STEPS) { if (owner) a.p[o] = a.sigp[i]; continue; }
+            float po = 0.f, fo = 0.f, sg = 0.f;
+            if (owner) {
+                if (MODE == MODE_UPDATE) sg = a.sigp[i];
+                if (MODE == MODE_UPDATE || MODE == MODE_ENERGY) { po = a.p[o]; fo = a.f[o]; }
+            }
+            const float *win = ubl + (f * R - r0) + SR * (f * C - c0);          // window row of kernel row -wpad
+            float s = 0.f;
+            if ((f & 1) == 0) {
+                // even zoom: these rows start on an even row of the window: 8-byte reads against the
+                // kernel table that is shifted down by the padding rows
+                const int m2 = g.MPq >> 1;
+                for (int nn = sub; nn < g.CW; nn += LPP) {
+                    const float2 *col = reinterpret_cast<const float2 *>(win + SR * nn);
+                    const float2 *ck = reinterpret_cast<const float2 *>(ckq + g.MPq * nn);
+                    for (int k = 0; k < m2; ++k) {
+                        const float2 v = col[k], c2 = ck[k];
+                        s += c2.x * v.x + c2.y * v.y;
+                    }
+                }
+            } else {
+                for (int nn = sub; nn < g.CW; nn += LPP) {
+                    const float *col = win + wpad + SR * nn;
+                    const float *ck = ckq + wpad + g.MPq * nn;
+                    for (int mm = 0; mm < g.CH; ++mm) s += ck[mm] * col[mm];
+                }
+            }
+            for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off, 64);
+            if (owner) {
+                if (a.pcorr) s += a.pcorr[o];
+                if (MODE == MODE_RAW) {
+                    a.p[o] = s;
+                } else if (MODE == MODE_ENERGY) {
+                    epart += fabsf(s - fo);
+                    diag[0] += s * s;
+                    diag[1] += box_residual2(s - fo, po, 1.f);
+                } else {
+                    const float pn = fminf(fmaxf(po + sg * (s - fo), -1.f), 1.f);
+                    a.p[o] = pn;
+                    if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; }
+                }
+            }
+        }
+    }
+    if (!QUAD && !LANES && MODE != MODE_STEPS && !ABL(512)) {
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         for (int lp = lane; lp < nlr; lp += 64) {
             const int Rl = lp % LRR, Cl = lp / LRR;
             float s = 0.f;
-            if (VEC) {
+            if (VEC && F == 4) {
                 // lanes are 16 bytes apart (conflict-free), the kernel rows are a broadcast
                 const int mq = g.MPq >> 2;
                 for (int nn = wv; nn < g.CW; nn += NWV) {
@@ -1162,7 +1242,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
                 }
             } else {
                 for (int nn = wv; nn < g.CW; nn += NWV) {
-                    const float *col = ubl + f * Rl + SR * (f * Cl + nn);
+                    const float *col = ubl + wpad + f * Rl + SR * (f * Cl + nn);
                     const float *ck = a.cker + g.CH * nn;
                     for (int mm = 0; mm < g.CH; ++mm) s += ck[mm] * col[mm];
                 }
@@ -1172,7 +1252,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
         __syncthreads();
     }
     for (int lp = tid; lp < nlr; lp += MMC_THREADS) {
-        if (QUAD && MODE != MODE_STEPS) break;
+        if (LANES || (QUAD && MODE != MODE_STEPS)) break;
         const int Rl = lp % LRR, Cl = lp / LRR;
         const int R = r0 / f + Rl, C = c0 / f + Cl;
         if (R >= g.ny || C >= g.nx) continue;
@@ -1643,8 +1723,9 @@ static void launch_dual4_m(const Geom &g0, const Arrays &a, int t0, int nf, int 
     const Geom g = with_launch_frames(g0, nf);
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const int f = g.f;
-    const int SRmax = g.SRp > TILE_R + g.CH - f ? g.SRp : TILE_R + g.CH - f;
-    const size_t lds = (size_t)(((SRmax * (TILE_C + g.CW - f) + 3) & ~3) + (((MMC_THREADS / 64) * (TILE_R / f) * (TILE_C / f) + 3) & ~3) +
+    const int fe = (TILE_R % f == 0 && TILE_C % f == 0) ? f : 1;
+    const int SRmax = g.SRp > TILE_R + g.CH - fe ? g.SRp : TILE_R + g.CH - fe;
+    const size_t lds = (size_t)(((SRmax * (TILE_C + g.CW - fe) + 3) & ~3) + (((MMC_THREADS / 64) * (TILE_R / f) * (TILE_C / f) + 3) & ~3) +
                                 g.MPq * g.CW + 2 * MMC_WARP_MAX) * sizeof(float) + lds_pad();
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
@@ -1667,7 +1748,7 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
         const int total = a.ne * nf;
         hipLaunchKernelGGL(k_corr_p, dim3((total + MMC_THREADS - 1) / MMC_THREADS), dim3(MMC_THREADS), 0, s, g, a, t0, nf);
     }
-    if (g.Ny % 4 == 0 && TILE_R % g.f == 0 && TILE_C % g.f == 0 && !ABL(16)) {
+    if (g.Ny % 4 == 0 && !ABL(16)) {
         // fused row-quad kernel: regulariser duals and data-term dual in one launch
         if (g.f == 4) launch_dual4<4>(g, a, t0, nf, mode, reduce, s);
         else launch_dual4<0>(g, a, t0, nf, mode, reduce, s);

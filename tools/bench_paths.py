@@ -34,6 +34,10 @@ for name, factor, ny, nx, method, kernel, aa in CASES:
     s.solve(20, 0.0, 0)
     st = s.solve(iters, 0.0, 0)
     ms = st["seconds"] / iters * 1e3
-    print("%-48s %4dx%4dx%d  %.3f ms per iteration, %6.0f HR Mpx*iter/s" % (name, Ny, Nx, L, ms, Ny * Nx * L / ms / 1e3))
+    s.set_profiling(True)
+    s.solve(iters, 0.0, 0)
+    pr = s.get_profile()
+    print("%-48s %4dx%4dx%d  %.3f ms per iteration, %6.0f HR Mpx*iter/s  (primal %.3f, dual %.3f)"
+          % (name, Ny, Nx, L, ms, Ny * Nx * L / ms / 1e3, pr["primal_ms"], pr["dual_reg_ms"] + pr["dual_data_ms"]))
     sys.stdout.flush()
     s.close()
