@@ -753,12 +753,15 @@ def operator_norm(P, iters=200, seed=0):
     return float(np.sqrt(s))
 
 
-def pdhg_scalar(P, iters, x=None, y=None, ratio=1.0, norm=None, callback=None, every=0):
+def pdhg_scalar(P, iters, x=None, y=None, ratio=1.0, norm=None, callback=None, every=0, restart_every=0, score=None):
     """Plain Chambolle-Pock PDHG with ONE scalar step pair, tau*sigma*|K|^2 = 0.98^2 and
     tau/sigma = ratio, dual step first:
         y+ = prox_{sigma F*}(y + sigma K xb);  x+ = prox_G(x - tau K'y+);  xb = 2x+ - x.
     It shares neither the diagonal preconditioning nor the update order of pdhg() and of the
-    HIP sweeps; it exists to reach the optimum of the same model by another route."""
+    HIP sweeps; it exists to reach the optimum of the same model by another route.
+    restart_every > 0: every that many iterations the run continues from the average of the
+    iterates since the last restart when score(x, y) (smaller is better, e.g. the gap) says the
+    average is the better point (restarted averaged PDHG)."""
     L = operator_norm(P) if norm is None else norm
     tau = 0.98 / L * np.sqrt(ratio)
     sigma = 0.98 / L / np.sqrt(ratio)
@@ -766,11 +769,23 @@ def pdhg_scalar(P, iters, x=None, y=None, ratio=1.0, norm=None, callback=None, e
     y = (P.y0 if y is None else y).astype(np.float64)
     xb = x.copy()
     S = np.full(P.K.shape[0], sigma)
+    xs, ys, cnt = np.zeros_like(x), np.zeros_like(y), 0
     for it in range(iters):
         y = prox_Fstar(P, y + sigma * (P.K @ xb), S)
         xn = prox_G(P, x - tau * (P.KT @ y))
         xb = 2.0 * xn - x
         x = xn
+        if restart_every:
+            xs += x
+            ys += y
+            cnt += 1
+            if (it + 1) % restart_every == 0:
+                xa, ya = xs / cnt, ys / cnt
+                if score(xa, ya) < score(x, y):
+                    x, y, xb = xa, ya, xa.copy()
+                xs[:] = 0.0
+                ys[:] = 0.0
+                cnt = 0
         if callback is not None and every and (it + 1) % every == 0:
             if callback(it + 1, x, y):
                 break

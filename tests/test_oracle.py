@@ -193,3 +193,21 @@ def test_golden_tube3_crop_super_resolution_beats_bicubic():
     psnr_sr = orc.psnr_central(u, truth)
     psnr_bic = orc.psnr_central(P.u_up, truth)
     assert psnr_sr > psnr_bic + 0.5, (psnr_sr, psnr_bic)
+
+
+def test_preconditioned_iteration_reaches_the_independent_optimum():
+    """oracle.pdhg (diagonal preconditioning, primal step first: the rule the HIP sweeps follow) at the
+    reference's iteration cap against the bounds of the optimal energy that scalar-step PDHG with restarts
+    reached on the same matrices (tests/golden/converged.npz, tests/golden/make_converged.py)."""
+    gold = np.load(os.path.join(GOLD, "converged.npz"))
+    s = np.load(os.path.join(GOLD, "synthetic_small.npz"))
+    for name, kappa, cap in (("ic", 0.25, 7500), ("add", float("nan"), 2500)):
+        upper, lower = float(gold["synthetic_%s_energy" % name]), float(gold["synthetic_%s_lower" % name])
+        assert 0.0 <= upper - lower <= 1e-6 * upper
+        P = orc.build_problem(s["f"], s["v"], k=s["k"], kappa=kappa)
+        x, y, _ = orc.pdhg(P, cap)
+        e = orc.primal_energy(P, x)
+        assert lower * (1 - 1e-9) <= e <= upper * (1 + 1e-4), (lower, e, upper)
+        # and the dual side: the gap of the preconditioned iterate brackets the same optimum
+        wb = 2.0 * np.abs(x[P.M:]).max() + 1.0 if len(P.primal) == 2 else 0.0
+        assert orc.dual_energy(P, y, wb) <= upper * (1 + 1e-9)

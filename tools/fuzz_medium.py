@@ -1,6 +1,6 @@
 """Random medium-sized configurations of the coupled solve (tens to hundreds of 64 x 16 tiles per frame,
 2 to 6 frames) against the C restatement (oracle/mmc_oracle_c.c): every model and flow direction, zoom 4 with
-'average' or 'stride', zoom 2 and 3 with 'stride', smooth / random / integer flows with and without a few
+'average' or 'stride', zoom 2, 3, 5, 6 and 8 with 'stride' (row counts that are and are not multiples of 4), smooth / random / integer flows with and without a few
 far outliers, occlusion maps, with and without blur.  Prints the worst relative error; exits non-zero on a miss.
 usage: python tools/fuzz_medium.py [cases] [seed]"""
 import os
@@ -22,10 +22,10 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst, bad = 0.0, 0
 for n in range(cases):
-    factor = int(rng.choice([4, 4, 4, 2, 3]))
-    ny, nx = int(rng.integers(40, 160)), int(rng.integers(40, 200))
-    if factor == 2:
-        ny, nx = 2 * ny, 2 * nx
+    factor = int(rng.choice([4, 4, 4, 2, 2, 3, 3, 5, 6, 8]))
+    ny, nx = int(rng.integers(40, 160)) * 4 // factor, int(rng.integers(40, 200)) * 4 // factor
+    if factor in (3, 5, 6) and rng.random() < 0.75:
+        ny = (ny + 3) // 4 * 4                       # a row count the row-quad sweeps take (zoom factors that do not divide the tile)
     nc = int(rng.integers(2, 7))
     sampling = "average" if factor == 4 and rng.random() < 0.6 else "stride"
     k = orc.fspecial_gaussian(int(rng.choice([3, 5, 7])), 0.8) if rng.random() < 0.8 else None
