@@ -86,7 +86,8 @@ template <typename T>
 static int dev_alloc(mmc_handle *h, T **ptr, size_t count, bool zero = true, size_t skew = 0) {
     void *p = nullptr;
     size_t bytes = (count ? count : 1) * sizeof(T);
-    HIPCHK(h, hipMalloc(&p, bytes + skew));
+    // + 16: the last row quad of a plane is loaded whole even when its column ends after one to three rows
+    HIPCHK(h, hipMalloc(&p, bytes + skew + 16));
     h->allocs.push_back(p);
     p = static_cast<char *>(p) + skew;
     if (zero) HIPCHK(h, hipMemsetAsync(p, 0, bytes, h->stream));
@@ -408,7 +409,7 @@ static int create_handle(const mmc_params *p, bool geometry_only, mmc_handle **o
             if (hipMemsetAsync(*per_px[i], 0, fs * sizeof(float), h->stream) != hipSuccess) { h->err = "hipMemsetAsync failed"; return bail(MMC_ERR_HIP); }
         }
     }
-    if ((rc = dev_alloc(h, &a.idq, (size_t)h->L * ((size_t)g.N / 4 + 1), true, 13 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.idq, (size_t)h->L * MMC_IDQ_PER_FRAME(g), true, 13 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.p, (size_t)h->L * g.n, true, 14 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.f, (size_t)h->L * g.n, true, 15 * PLANE_SKEW_DEFAULT)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.cA, (size_t)g.N)) != MMC_OK) return bail(rc);
@@ -901,7 +902,7 @@ static int build_data_operator(mmc_handle *h) {
         void *pc = nullptr, *uc = nullptr;
         HIPCHK(h, hipMalloc(&pc, (size_t)h->L * g.n * sizeof(float)));
         h->eallocs.push_back(pc);
-        HIPCHK(h, hipMalloc(&uc, (size_t)h->L * g.N * sizeof(float)));
+        HIPCHK(h, hipMalloc(&uc, (size_t)h->L * g.N * sizeof(float) + 16));      // + 16: see dev_alloc
         h->eallocs.push_back(uc);
         HIPCHK(h, hipMemsetAsync(pc, 0, (size_t)h->L * g.n * sizeof(float), h->stream));
         HIPCHK(h, hipMemsetAsync(uc, 0, (size_t)h->L * g.N * sizeof(float), h->stream));

@@ -34,6 +34,9 @@ struct Taps {
 // the closed pixel domain (or NaN) masks the row.  Float32 arithmetic in this
 // exact order; the CPU oracle repeats it to reach the same floor() decisions.
 __device__ __forceinline__ Taps make_taps(const Geom &g, int r, int c, float vx, float vy) {
+    // Each operation is rounded on its own (no fused multiply-add, e.g. of 1 - a into the products):
+    // every kernel that forms the taps of a pixel gets the same bits, as the oracle does.
+#pragma clang fp contract(off)
     Taps t;
     float y = (float)r + vy;
     float x = (float)c + vx;
@@ -88,6 +91,12 @@ __device__ __forceinline__ double fx_scaled(float s) { return (double)s * 109951
 __device__ __forceinline__ float from_fx(fx64 v) {
     const double d = (double)(int)(unsigned)(v >> 32) * 4294967296.0 + (double)(unsigned)(v & 0xffffffffull);
     return (float)(d * (1.0 / 1099511627776.0));
+}
+// The fixed-point sum plus a small integer, rounded to float once (the sum of the scattered tap
+// weights of a pixel plus its count of identity entries: every path that forms it gets the same bits).
+__device__ __forceinline__ float from_fx_plus(fx64 v, int n) {
+    const double d = (double)(int)(unsigned)(v >> 32) * 4294967296.0 + (double)(unsigned)(v & 0xffffffffull);
+    return (float)(d * (1.0 / 1099511627776.0) + (double)n);
 }
 __device__ __forceinline__ void fx_add(fx64 *acc, float w, double s40) { atomicAdd(acc, to_fx((double)w, s40)); }
 

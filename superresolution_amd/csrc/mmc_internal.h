@@ -57,6 +57,9 @@ static inline FastDiv make_fastdiv(unsigned d) {
     return r;
 }
 
+// identity bits (Arrays::idq): one byte per row quad, ceil(Ny / 4) quads per column, column after column
+#define MMC_IDQ_PER_FRAME(g) ((size_t)(((g).Ny + 3) >> 2) * (size_t)(g).Nx)
+
 struct Geom {
     int Ny, Nx, N;             // high-resolution frame
     int ny, nx, n;             // low-resolution frame

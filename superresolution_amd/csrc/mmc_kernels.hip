@@ -39,159 +39,36 @@ __device__ __forceinline__ void dual_objective_terms(float (&d)[4], float KTu, f
 // --------------------------------------------------------------------------
 // primal sweep
 // --------------------------------------------------------------------------
-// MODE_UPDATE: u,w <- prox_G(x - T K'y); ub,wb <- 2x+ - x
-// MODE_RAW   : ub,wb <- K'y           (test hook)
-// MODE_STEPS : ub,wb <- tau_u, tau_w  (test hook)
-template <int MODEL, int MODE, bool REDUCE>
-__global__ __launch_bounds__(MMC_THREADS) void k_primal(Geom g, Arrays a, int t0) {
-    __shared__ fx64 acc1[TILE_R * TILE_C];
-    __shared__ fx64 acc2[TILE_R * TILE_C];
-    const int t = t0 + blockIdx.y;
-    const int tile = blockIdx.x;
-    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
-    const int r0 = tr * TILE_R, c0 = tc * TILE_C;
-    const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
-
-    for (int k = threadIdx.x; k < TILE_R * TILE_C; k += MMC_THREADS) {
-        acc1[k] = 0;
-        if (MODEL == MODEL_IC) acc2[k] = 0;
-    }
-    __syncthreads();
-
-    // --- scatter part of W': pairs whose warp samples THIS frame -----------
-    if (MODE != MODE_STEPS) {
-        for (int which = 0; which < 2; ++which) {
-            const int q = which == 0 ? t - 1 : t;
-            if (!pair_exists(g, q)) continue;
-            const bool isIF = pair_is_IF(g, q);
-            if ((which == 0) != isIF) continue;   // q=t-1 warps into t iff I-F; q=t iff F-I
-            const size_t slot = (size_t)(q + 1) * g.ntiles + tile;
-            const int *bb = a.bbox + slot * 4;
-            const int rmin = bb[0], rmax = bb[1], cmin = bb[2], cmax = bb[3];
-            const int nr = rmax - rmin + 1, total = (rmax < rmin || cmax < cmin) ? 0 : nr * (cmax - cmin + 1);
-            const int ob = a.ovf_ptr[slot], novf = a.ovf_ptr[slot + 1] - ob;
-            const float *vx = FR(a.vx, q), *vy = FR(a.vy, q);
-            const float *s1p = FR(a.g1t, q), *s2p = FR(a.g2t, q);
-            // the source rectangle, then the sources outside it
-            for (int idx = threadIdx.x; idx < total + novf; idx += MMC_THREADS) {
-                int r, c, j;
-                if (idx < total) { r = rmin + idx % nr; c = cmin + idx / nr; j = r + g.Ny * c; }
-                else { j = a.ovf_idx[ob + idx - total]; c = j / g.Ny; r = j - c * g.Ny; }
-                Taps tp = make_taps(g, r, c, vx[j], vy[j]);
-                if (!tp.valid) continue;
-                const float s1 = s1p[j];
-                float s2 = 0.f;
-                if (MODEL == MODEL_IC) s2 = kap * s2p[j] + g.wsgn * s1;
-                const double d1 = fx_scaled(s1), d2 = fx_scaled(s2);
-                const int a0 = tp.r0 - r0, a1 = tp.r1 - r0, b0 = tp.c0 - c0, b1 = tp.c1 - c0;
-                const bool ra0 = (unsigned)a0 < TILE_R, ra1 = (unsigned)a1 < TILE_R;
-                const bool cb0 = (unsigned)b0 < TILE_C, cb1 = (unsigned)b1 < TILE_C;
-                if (ra0 && cb0) { fx_add(&acc1[a0 + TILE_R * b0], tp.w00, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b0], tp.w00, d2); }
-                if (ra1 && cb0) { fx_add(&acc1[a1 + TILE_R * b0], tp.w10, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b0], tp.w10, d2); }
-                if (ra0 && cb1) { fx_add(&acc1[a0 + TILE_R * b1], tp.w01, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a0 + TILE_R * b1], tp.w01, d2); }
-                if (ra1 && cb1) { fx_add(&acc1[a1 + TILE_R * b1], tp.w11, d1); if (MODEL == MODEL_IC) fx_add(&acc2[a1 + TILE_R * b1], tp.w11, d2); }
-            }
-        }
-        __syncthreads();
-    }
-
-    // --- identity part of W': pairs whose -Id block sits on THIS frame ------
-    const bool idA = pair_exists(g, t) && pair_is_IF(g, t);              // -Id of pair t
-    const bool idB = pair_exists(g, t - 1) && !pair_is_IF(g, t - 1);     // -Id of pair t-1
-    const float *idA1 = FR(a.g1t, t), *idA2 = FR(a.g2t, t);
-    const float *idB1 = FR(a.g1t, t - 1), *idB2 = FR(a.g2t, t - 1);
-
-    float *u = FR(a.u, t), *w = FR(a.w, t), *ub = FR(a.ub, t), *wb = FR(a.wb, t);
-    const float *g1x = FR(a.g1x, t), *g1y = FR(a.g1y, t), *g2x = FR(a.g2x, t), *g2y = FR(a.g2y, t);
-    const float *cW = FR(a.cW, t);
-    const float *p = a.p + (size_t)t * g.n;
-    float part[2] = {0.f, 0.f};
-    float dob[4] = {0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int s = 0; s < TILE_R * TILE_C / MMC_THREADS; ++s) {
-        const int k = threadIdx.x + MMC_THREADS * s;
-        const int r = r0 + (k % TILE_R), c = c0 + (k / TILE_R);
-        if (r >= g.Ny || c >= g.Nx) continue;
-        const int j = r + g.Ny * c;
-        const float cgrad = (float)((c < g.Nx - 1) + (c > 0) + (r < g.Ny - 1) + (r > 0));
-        const float cw = cW[j] * g.inv_h;
-        float tau_u, tau_w = 0.f;
-        const bool isfix = MODEL == MODEL_IC && g.fixed && g.frame_begin + t == 0;   // identity rows of q1, q2 (:560-561)
-        if (MODEL == MODEL_IC) {
-            tau_u = fast_rcp(a.cA[j] + cw + kap * cgrad + (isfix ? 1.f : 0.f));
-            tau_w = fast_rcp((1.f + kap) * (cw + cgrad) + (isfix ? 1.f : 0.f));
-        } else {
-            tau_u = fast_rcp(a.cA[j] + cw + cgrad);
-        }
-        if (MODE == MODE_STEPS) {
-            ub[j] = tau_u;
-            if (MODEL == MODEL_IC) wb[j] = tau_w;
-            continue;
-        }
-        float Wt1 = from_fx(acc1[k]), Wt2 = (MODEL == MODEL_IC) ? from_fx(acc2[k]) : 0.f;
-        if (idA) {
-            const float s1 = idA1[j];
-            Wt1 -= s1;
-            if (MODEL == MODEL_IC) Wt2 -= kap * idA2[j] + g.wsgn * s1;
-        }
-        if (idB) {
-            const float s1 = idB1[j];
-            Wt1 -= s1;
-            if (MODEL == MODEL_IC) Wt2 -= kap * idB2[j] + g.wsgn * s1;
-        }
-        const float div1 = grad_adj(g, g1x, g1y, r, c, j);
-        const float ATp = gather_ATp(g, a.cker, p, r, c);
-        float KTu = ATp + g.inv_h * Wt1 + kap * div1;
-        if (a.ucorr) KTu += a.ucorr[(size_t)t * g.N + j];      // rows of A that deviate from the composite kernel
-        float KTw = 0.f;
-        if (MODEL == MODEL_IC) {
-            const float div2 = grad_adj(g, g2x, g2y, r, c, j);
-            KTw = g.inv_h * Wt2 - kap * div1 + div2;
-            if (isfix) { KTu += a.q1[j]; KTw += a.q2[j]; }
-        }
-        if (MODE == MODE_RAW) {
-            ub[j] = KTu;
-            if (MODEL == MODEL_IC) wb[j] = KTw;
-            continue;
-        }
-        if (MODE == MODE_DUALOBJ) {
-            dual_objective_terms(dob, KTu, KTw, u[j]);
-            continue;
-        }
-        const float uo = u[j];
-        const float un = fminf(fmaxf(uo - tau_u * KTu, 0.f), 1.f);   // G = ind[0,1], :495
-        u[j] = un;
-        ub[j] = 2.f * un - uo;
-        if (REDUCE) { part[0] += (un - uo) * (un - uo); part[1] += un * un; }
-        if (MODEL == MODEL_IC) {
-            const float wo = w[j];
-            const float wn = wo - tau_w * KTw;
-            w[j] = wn;
-            wb[j] = 2.f * wn - wo;
-            if (REDUCE) { part[0] += (wn - wo) * (wn - wo); part[1] += wn * wn; }
-        }
-    }
-    if (MODE == MODE_DUALOBJ) block_accumulate<4>(dob, a.sums, SUM_DUALOBJ);
-    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES);
-}
-
-// --------------------------------------------------------------------------
-// primal sweep, row-quad form (Ny % 4 == 0)
-// --------------------------------------------------------------------------
-// Same arithmetic as k_primal; each thread owns four consecutive rows of one
-// column so that every per-pixel array moves as one 16-byte access per lane.
+// MODE_UPDATE   : u,w <- prox_G(x - T K'y); ub,wb <- 2x+ - x
+// MODE_RAW      : ub,wb <- K'y                      (test hook)
+// MODE_STEPS    : ub,wb <- tau_u, tau_w from the cW plane; MODE_STEPS_UPD: as the update derives them (test hooks)
+// MODE_DUALOBJ  : the K'y terms of the dual objective and the primal optimality residual; writes nothing
+// Each thread owns a row quad: four consecutive rows of one column, so that every
+// per-pixel array moves as one 16-byte access per lane (the last quad of a column is
+// short when Ny is not a multiple of 4).
 // The low-res dual p of the tile and a zero-padded copy of the composite
 // kernel sit in LDS, which makes the interior A'p a branch-free Jr x Jc sum:
 // tap (jr,jc) of pixel row x = r - oy uses low-res row R = x/f - jr with
 // kernel row (x mod f) + f*jr; rows of the table beyond CH and low-res pixels
 // outside the frame hold zeros.
+// 16-byte accesses to the planes.  A column starts at a multiple of Ny floats, which is 16-byte aligned
+// only when Ny is a multiple of 4: the type says 4-byte alignment (global memory takes dwordx4
+// accesses at any dword address; LDS accesses elsewhere in this file stay aligned).
+typedef float rowquad_t __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void ld4(float (&d)[4], const float *p) {
-    const float4 v = *reinterpret_cast<const float4 *>(p);
+    const rowquad_t v = *reinterpret_cast<const rowquad_t *>(p);
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 }
 __device__ __forceinline__ void st4(float *p, const float (&s)[4]) {
-    *reinterpret_cast<float4 *>(p) = make_float4(s[0], s[1], s[2], s[3]);
+    rowquad_t v = {s[0], s[1], s[2], s[3]};
+    *reinterpret_cast<rowquad_t *>(p) = v;
+}
+// The last quad of a column holds nv < 4 rows when Ny is not a multiple of 4; what follows it in memory
+// is the top of the next column.
+__device__ __forceinline__ void st4m(float *p, const float (&s)[4], int nv) {
+    if (nv >= 4) { st4(p, s); return; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (i < nv) p[i] = s[i];
 }
 
 // Tuning switches of the row-quad sweeps (defaults are the measured best).
@@ -256,6 +133,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
     const int r = r0 + 4 * rq, c = c0 + lc;
     const bool active = r < g.Ny && c < g.Nx;
     const int j = active ? r + g.Ny * c : 0;
+    const int nv = F == 4 ? 4 : min(g.Ny - r, 4);                       // rows of this quad inside the frame (zoom 4: Ny = 4 ny)
     const bool cl = c > 0, cr = c < g.Nx - 1;
     const bool idA = pair_exists(g, t) && pair_is_IF(g, t);            // -Id of pair t sits on this frame
     const bool idB = pair_exists(g, t - 1) && !pair_is_IF(g, t - 1);   // -Id of pair t-1
@@ -273,7 +151,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
         if (grpX && MODE == MODE_DUALOBJ) ld4(uo, FR(a.u, t) + j);      // no step sizes in this mode
         if (grpX && MODE != MODE_DUALOBJ) {
             if (!CWS) ld4(cWv, FR(a.cW, t) + j);
-            else idb = a.idq[(size_t)t * (g.N / 4 + 1) + (j >> 2)];
+            else idb = a.idq[(size_t)t * MMC_IDQ_PER_FRAME(g) + (size_t)(r >> 2) + (size_t)((g.Ny + 3) >> 2) * c];
             if (F == 4 && g.cA_margin > 0 && r >= g.cA_margin && r + 4 <= g.Ny - g.cA_margin &&
                 c >= g.cA_margin && c < g.Nx - g.cA_margin && !ABL(128)) {
                 // interior: period-4 pattern (row phase of quad row i is i)
@@ -437,9 +315,12 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
         const float fixc = isfix ? 1.f : 0.f;
         if (CWS) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cWv[i] = from_fx(acc3[4 * rq + i + TILE_R * lc]) + (float)((idb >> (2 * i)) & 3u);
+            for (int i = 0; i < 4; ++i) cWv[i] = from_fx_plus(acc3[4 * rq + i + TILE_R * lc], (int)((idb >> (2 * i)) & 3u));
         }
         auto compute_tau = [&]() {
+            // Every operation rounded on its own (no fused multiply-add picked by the compiler): the step
+            // sizes must not depend on which instantiation of this kernel computes them.
+#pragma clang fp contract(off)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float cgrad = (float)((int)cl + (int)cr + (int)(r + i > 0) + (int)(r + i < g.Ny - 1));
@@ -455,8 +336,8 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
         };
         if (MODE != MODE_DUALOBJ) compute_tau();
         if (MODE == MODE_STEPS || MODE == MODE_STEPS_UPD) {
-            st4(ub, tau_u);
-            if (MODEL == MODEL_IC) st4(wb, tau_w);
+            st4m(ub, tau_u, nv);
+            if (MODEL == MODEL_IC) st4m(wb, tau_w, nv);
         } else {
             float Wt1[4], Wt2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -562,31 +443,31 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                 for (int i = 0; i < 4; ++i) { KTu[i] += q1v[i]; KTw[i] += q2v[i]; }
             }
             if (MODE == MODE_RAW) {
-                st4(ub, KTu);
-                if (MODEL == MODEL_IC) st4(wb, KTw);
+                st4m(ub, KTu, nv);
+                if (MODEL == MODEL_IC) st4m(wb, KTw, nv);
             } else if (MODE == MODE_DUALOBJ) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dual_objective_terms(dob, KTu[i], KTw[i], uo[i]);
+                for (int i = 0; i < 4; ++i) if (i < nv) dual_objective_terms(dob, KTu[i], KTw[i], uo[i]);
             } else {
                 float un[4], ubn[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     un[i] = fminf(fmaxf(uo[i] - tau_u[i] * KTu[i], 0.f), 1.f);   // G = ind[0,1], :495
                     ubn[i] = 2.f * un[i] - uo[i];
-                    if (REDUCE) { part[0] += (un[i] - uo[i]) * (un[i] - uo[i]); part[1] += un[i] * un[i]; }
+                    if (REDUCE && i < nv) { part[0] += (un[i] - uo[i]) * (un[i] - uo[i]); part[1] += un[i] * un[i]; }
                 }
-                st4(u, un);
-                st4(ub, ubn);
+                st4m(u, un, nv);
+                st4m(ub, ubn, nv);
                 if (MODEL == MODEL_IC) {
                     float wn[4], wbn[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         wn[i] = wo[i] - tau_w[i] * KTw[i];
                         wbn[i] = 2.f * wn[i] - wo[i];
-                        if (REDUCE) { part[0] += (wn[i] - wo[i]) * (wn[i] - wo[i]); part[1] += wn[i] * wn[i]; }
+                        if (REDUCE && i < nv) { part[0] += (wn[i] - wo[i]) * (wn[i] - wo[i]); part[1] += wn[i] * wn[i]; }
                     }
-                    st4(w, wn);
-                    st4(wb, wbn);
+                    st4m(w, wn, nv);
+                    st4m(wb, wbn, nv);
                 }
             }
         }
@@ -596,221 +477,20 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
 }
 
 // --------------------------------------------------------------------------
-// dual sweep, regulariser part (g1, g2)
+// dual sweep: regulariser duals (g1, g2) and data-term dual (p) in one launch
 // --------------------------------------------------------------------------
-// MODE_UPDATE: g <- proj(g + S K xbar)
-// MODE_RAW   : g <- K xbar                     (test hook)
-// MODE_STEPS : g?t <- sigma of the group       (test hook)
-// MODE_ENERGY: sums[4] += alpha*sum ||(K x)_j|| (reads ub/wb pointers as given)
-template <int MODEL, int MODE, bool REDUCE>
-__global__ __launch_bounds__(MMC_THREADS) void k_dual(Geom g, Arrays a, int t0) {
-    const int t = t0 + blockIdx.y;
-    const int tile = blockIdx.x;
-    const int tc = fdiv(tile, g.dv_tiles_r), tr = tile - tc * g.tiles_r;
-    const int r0 = tr * TILE_R, c0 = tc * TILE_C;
-    const float kap = (MODEL == MODEL_IC) ? g.kappa : 1.f;
-    const bool pex = pair_exists(g, t);
-    const bool isIF = pair_is_IF(g, t);
-    const float *ub = FR(a.ub, t), *wb = FR(a.wb, t);
-    const float *ubW = FR(a.ub, isIF ? t + 1 : t), *wbW = FR(a.wb, isIF ? t + 1 : t);   // warped frame
-    const float *ubI = FR(a.ub, isIF ? t : t + 1), *wbI = FR(a.wb, isIF ? t : t + 1);   // identity frame
-    const float *vx = FR(a.vx, t), *vy = FR(a.vy, t);
-    float *g1t = FR(a.g1t, t), *g1x = FR(a.g1x, t), *g1y = FR(a.g1y, t);
-    float *g2t = FR(a.g2t, t), *g2x = FR(a.g2x, t), *g2y = FR(a.g2y, t);
-    float part[2] = {0.f, 0.f};
-    float diag[2] = {0.f, 0.f};      // MODE_ENERGY: |K x|^2, dual optimality residual^2
-
-#pragma unroll
-    for (int s = 0; s < TILE_R * TILE_C / MMC_THREADS; ++s) {
-        const int k = threadIdx.x + MMC_THREADS * s;
-        const int r = r0 + (k % TILE_R), c = c0 + (k / TILE_R);
-        if (r >= g.Ny || c >= g.Nx) continue;
-        const int j = r + g.Ny * c;
-        const bool hasx = c < g.Nx - 1, hasy = r < g.Ny - 1;
-
-        const float uc = ub[j];
-        const float ux = hasx ? ub[j + g.Ny] : uc;
-        const float uy = hasy ? ub[j + 1] : uc;
-        float wc = 0.f, wx = 0.f, wy = 0.f;
-        if (MODEL == MODEL_IC) {
-            wc = wb[j];
-            wx = hasx ? wb[j + g.Ny] : wc;
-            wy = hasy ? wb[j + 1] : wc;
-        }
-        // temporal rows: W xbar for this pair
-        bool valid = false;
-        float tu = 0.f, tw = 0.f;
-        if (pex) {
-            Taps tp = make_taps(g, r, c, vx[j], vy[j]);
-            valid = tp.valid;
-            if (valid) {
-                tu = sample(tp, ubW) - ubI[j];
-                if (MODEL == MODEL_IC) tw = sample(tp, wbW) - wbI[j];
-            }
-        }
-        float k1t, k1x, k1y, k2t = 0.f, k2x = 0.f, k2y = 0.f;
-        float rs1, rs2 = 0.f;
-        if (MODEL == MODEL_IC) {
-            // K1 (u - w), K1 = [W/h ; kappa G]  (:490-491);  K2 w, K2 = [kappa W/h ; G]  (:492)
-            k1t = (tu + g.wsgn * tw) * g.inv_h;
-            k1x = kap * ((ux - wx) - (uc - wc));
-            k1y = kap * ((uy - wy) - (uc - wc));
-            k2t = kap * tw * g.inv_h;
-            k2x = wx - wc;
-            k2y = wy - wc;
-            rs1 = fmaxf(valid ? 4.f * g.inv_h : 0.f, fmaxf(hasx ? 4.f * kap : 0.f, hasy ? 4.f * kap : 0.f));
-            rs2 = fmaxf(valid ? 2.f * kap * g.inv_h : 0.f, fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f));
-        } else {
-            k1t = tu * g.inv_h;
-            k1x = ux - uc;
-            k1y = uy - uc;
-            if (MODEL == MODEL_K1) {
-                rs1 = fmaxf(valid ? 2.f * g.inv_h : 0.f, fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f));
-            } else {   // additive: temporal row alone (rs1), spatial pair (rs2)
-                rs1 = valid ? 2.f * g.inv_h : 0.f;
-                rs2 = fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f);
-            }
-        }
-        const float sg1 = rs1 > 0.f ? fast_rcp(rs1) : 1.f;
-        const float sg2 = rs2 > 0.f ? fast_rcp(rs2) : 1.f;
-
-        if (MODE == MODE_RAW) {
-            g1t[j] = k1t; g1x[j] = k1x; g1y[j] = k1y;
-            if (MODEL == MODEL_IC) { g2t[j] = k2t; g2x[j] = k2x; g2y[j] = k2y; }
-            continue;
-        }
-        if (MODE == MODE_STEPS) {
-            g1t[j] = sg1;
-            g2t[j] = sg2;
-            continue;
-        }
-        if (MODE == MODE_ENERGY) {
-            diag[0] += k1t * k1t + k1x * k1x + k1y * k1y + k2t * k2t + k2x * k2x + k2y * k2y;
-            if (MODEL == MODEL_IC) {
-                part[0] += g.radius1 * sqrtf(k1t * k1t + k1x * k1x + k1y * k1y) +
-                           g.radius2 * sqrtf(k2t * k2t + k2x * k2x + k2y * k2y);
-                diag[1] += ball_residual2(k1t, k1x, k1y, g1t[j], g1x[j], g1y[j], g.radius1) +
-                           ball_residual2(k2t, k2x, k2y, g2t[j], g2x[j], g2y[j], g.radius2);
-                if (g.fixed && g.frame_begin + t == 0) {      // identity rows of q1, q2: dF* = {x0}
-                    const float du = uc - a.u0[j], dw = wc - a.w0[j];
-                    diag[0] += uc * uc + wc * wc;
-                    diag[1] += du * du + dw * dw;
-                }
-            } else if (MODEL == MODEL_K1) {
-                part[0] += g.radius1 * sqrtf(k1t * k1t + k1x * k1x + k1y * k1y);
-                diag[1] += ball_residual2(k1t, k1x, k1y, g1t[j], g1x[j], g1y[j], g.radius1);
-            } else {
-                part[0] += g.radius1 * fabsf(k1t) + g.radius2 * sqrtf(k1x * k1x + k1y * k1y);
-                diag[1] += box_residual2(k1t, g1t[j], g.radius1) + ball_residual2(0.f, k1x, k1y, 0.f, g1x[j], g1y[j], g.radius2);
-            }
-            continue;
-        }
-        // MODE_UPDATE
-        const float o1t = g1t[j], o1x = g1x[j], o1y = g1y[j];
-        float n1t, n1x, n1y;
-        if (MODEL == MODEL_ADD) {
-            // |g1| <= alpha (:532) on the temporal row, ||(gx,gy)|| <= alpha (:533)
-            n1t = valid ? fminf(fmaxf(o1t + sg1 * k1t, -g.radius1), g.radius1) : 0.f;
-            n1x = o1x + sg2 * k1x;
-            n1y = o1y + sg2 * k1y;
-            const float sc = ball_scale(n1x * n1x + n1y * n1y, g.radius2);
-            n1x *= sc; n1y *= sc;
-        } else {
-            // ||(gt,gx,gy)||_2 <= radius (:497, :513)
-            n1t = valid ? o1t + sg1 * k1t : 0.f;
-            n1x = o1x + sg1 * k1x;
-            n1y = o1y + sg1 * k1y;
-            const float sc = ball_scale(n1t * n1t + n1x * n1x + n1y * n1y, g.radius1);
-            n1t *= sc; n1x *= sc; n1y *= sc;
-        }
-        g1t[j] = n1t; g1x[j] = n1x; g1y[j] = n1y;
-        if (REDUCE) {
-            part[0] += (n1t - o1t) * (n1t - o1t) + (n1x - o1x) * (n1x - o1x) + (n1y - o1y) * (n1y - o1y);
-            part[1] += n1t * n1t + n1x * n1x + n1y * n1y;
-        }
-        if (MODEL == MODEL_IC) {
-            const float o2t = g2t[j], o2x = g2x[j], o2y = g2y[j];
-            float n2t = valid ? o2t + sg2 * k2t : 0.f;
-            float n2x = o2x + sg2 * k2x;
-            float n2y = o2y + sg2 * k2y;
-            const float sc = ball_scale(n2t * n2t + n2x * n2x + n2y * n2y, g.radius2);
-            n2t *= sc; n2x *= sc; n2y *= sc;
-            g2t[j] = n2t; g2x[j] = n2x; g2y[j] = n2y;
-            if (REDUCE) {
-                part[0] += (n2t - o2t) * (n2t - o2t) + (n2x - o2x) * (n2x - o2x) + (n2y - o2y) * (n2y - o2y);
-                part[1] += n2t * n2t + n2x * n2x + n2y * n2y;
-            }
-            if (g.fixed && g.frame_begin + t == 0) {
-                // q <- q + (xbar - x0): F*(q) = <x0, q>, identity rows, step 1 (:560-564)
-                const float q1o = a.q1[j], q2o = a.q2[j];
-                const float q1n = q1o + (uc - a.u0[j]), q2n = q2o + (wc - a.w0[j]);
-                a.q1[j] = q1n; a.q2[j] = q2n;
-                if (REDUCE) {
-                    part[0] += (q1n - q1o) * (q1n - q1o) + (q2n - q2o) * (q2n - q2o);
-                    part[1] += q1n * q1n + q2n * q2n;
-                }
-            }
-        }
-    }
-    if (MODE == MODE_ENERGY) { float e[4] = {part[0], 0.f, diag[0], diag[1]}; block_accumulate<4>(e, a.sums, SUM_ENERGY); }
-    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES + 2);
-}
-
-// --------------------------------------------------------------------------
-// dual sweep, data part (p):  p <- clamp(p + s (A ub - f), -1, 1)   (:496)
-// --------------------------------------------------------------------------
-template <int MODE, bool REDUCE>
-__global__ __launch_bounds__(MMC_THREADS) void k_dual_p(Geom g, Arrays a, int t0, int nframes) {
-    const size_t idx = (size_t)blockIdx.x * MMC_THREADS + threadIdx.x;
-    float part[2] = {0.f, 0.f};
-    float diag[2] = {0.f, 0.f};      // MODE_ENERGY: |K x|^2, dual optimality residual^2
-    if (idx < (size_t)g.n * nframes) {
-        const int t = t0 + (int)(idx / g.n);
-        const int i = (int)(idx % g.n);
-        const int R = i % g.ny, C = i / g.ny;
-        const float *ub = FR(a.ub, t);
-        float acc = 0.f;
-        for (int nn = 0; nn < g.CW; ++nn) {
-            const int cc = min(max(g.f * C + g.ox + nn, 0), g.Nx - 1);
-            const float *col = ub + (size_t)g.Ny * cc;
-            for (int mm = 0; mm < g.CH; ++mm) {
-                const int rr = min(max(g.f * R + g.oy + mm, 0), g.Ny - 1);
-                acc += a.cker[mm + g.CH * nn] * col[rr];
-            }
-        }
-        const size_t o = (size_t)t * g.n + i;
-        const float sg = a.sigp[i];
-        if (a.pcorr) acc += a.pcorr[o];
-        if (MODE == MODE_RAW) {
-            a.p[o] = acc;
-        } else if (MODE == MODE_STEPS) {
-            a.p[o] = sg;
-        } else if (MODE == MODE_ENERGY) {
-            part[0] = fabsf(acc - a.f[o]);
-            diag[0] = acc * acc;
-            diag[1] = box_residual2(acc - a.f[o], a.p[o], 1.f);
-        } else {
-            const float po = a.p[o];
-            const float pn = fminf(fmaxf(po + sg * (acc - a.f[o]), -1.f), 1.f);
-            a.p[o] = pn;
-            if (REDUCE) { part[0] = (pn - po) * (pn - po); part[1] = pn * pn; }
-        }
-    }
-    if (MODE == MODE_ENERGY) { float e[3] = {part[0], diag[0], diag[1]}; block_accumulate<3>(e, a.sums, SUM_ENERGY + 1); }
-    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES + 2);
-}
-
-// --------------------------------------------------------------------------
-// dual sweep, row-quad form with the data-term update fused in
-// --------------------------------------------------------------------------
-// Needs Ny % 4 == 0.  Each thread owns four consecutive rows of one column for
+// MODE_UPDATE: g <- proj(g + S K xbar), p <- clamp(p + s (A xbar_u - f), -1, 1)   (:496-498)
+// MODE_RAW   : g, p <- K xbar                  (test hook)
+// MODE_STEPS : g?t <- sigma of the group, p <- sigma of the data rows   (test hook)
+// MODE_ENERGY: primal energy, |K x|^2 and the dual optimality residual at (ub, wb) as given; writes nothing
+// Each thread owns a row quad (four consecutive rows of one column) for
 // the regulariser duals.  The workgroup also stages xbar_u of its tile plus the
 // blur halo in LDS (replicate border applied while staging) and updates the
 // low-res duals p it owns from it: those whose first high-res pixel (f R, f C)
 // lies in the tile.  Groups of adjacent lanes share a low-res pixel and split
 // the composite-kernel columns among them.
 template <int MODEL, int MODE, bool REDUCE, int F>
-__global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arrays a, int t0, int nf) {
+__global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     const int f = F > 0 ? F : g.f;
     const int tid = threadIdx.x;
@@ -864,6 +544,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
     const int r = r0 + 4 * rq, c = c0 + lc;
     const bool active = r < g.Ny && c < g.Nx;
     const int j = active ? r + g.Ny * c : 0;
+    const int nv = F == 4 ? 4 : min(g.Ny - r, 4);       // rows of this quad inside the frame (zoom 4: Ny = 4 ny)
     const bool hasx = c < g.Nx - 1;
 
     // The data-term window of xbar_u also holds this quad's right neighbour column and the row below it
@@ -909,7 +590,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
             if (4 * kq < SR) {
                 const float *src = ub + wr0 + 4 * kq + g.Ny * wc0;
                 for (int kc = tid >> 5; kc < SC; kc += MMC_THREADS / 32)
-                    *reinterpret_cast<float4 *>(ubl + 4 * kq + SR * kc) = *reinterpret_cast<const float4 *>(src + g.Ny * kc);
+                    { float v4[4]; ld4(v4, src + g.Ny * kc); *reinterpret_cast<float4 *>(ubl + 4 * kq + SR * kc) = make_float4(v4[0], v4[1], v4[2], v4[3]); }
             }
         } else {
             const float inv_sr = fast_rcp((float)SR);
@@ -933,12 +614,15 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
             if (kr < 0) { --kc; kr += QR; }
             if (kr >= QR) { ++kc; kr -= QR; }
             const int src = wrlo + 4 * kr + g.Ny * (wclo + kc);
-            const float4 vu = *reinterpret_cast<const float4 *>(ubW + src);
+            float t4[4];
+            ld4(t4, ubW + src);
+            const float4 vu = make_float4(t4[0], t4[1], t4[2], t4[3]);
             float *du = wu + 4 * kr + WP * kc;
             if (MMC_TAP_ODD_PITCH) { du[0] = vu.x; du[1] = vu.y; du[2] = vu.z; du[3] = vu.w; }
             else *reinterpret_cast<float4 *>(du) = vu;
             if (MODEL == MODEL_IC) {
-                const float4 vw = *reinterpret_cast<const float4 *>(wbW + src);
+                ld4(t4, wbW + src);
+                const float4 vw = make_float4(t4[0], t4[1], t4[2], t4[3]);
                 float *dw = ww + 4 * kr + WP * kc;
                 if (MMC_TAP_ODD_PITCH) { dw[0] = vw.x; dw[1] = vw.y; dw[2] = vw.z; dw[3] = vw.w; }
                 else *reinterpret_cast<float4 *>(dw) = vw;
@@ -969,7 +653,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
             const float wy = i < 3 ? wc[i < 3 ? i + 1 : 3] : wbelow;
             float tu = 0.f, tw = 0.f;
             valid[i] = false;
-            if (pex && !ABL(256)) {
+            if (pex && i < nv && !ABL(256)) {
                 Taps tp = make_taps(g, r + i, c, fvx[i], fvy[i]);
                 valid[i] = tp.valid;
                 if (tp.valid) {
@@ -1015,14 +699,15 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
         float *g1t = FR(a.g1t, t) + j, *g1x = FR(a.g1x, t) + j, *g1y = FR(a.g1y, t) + j;
         float *g2t = FR(a.g2t, t) + j, *g2x = FR(a.g2x, t) + j, *g2y = FR(a.g2y, t) + j;
         if (MODE == MODE_RAW) {
-            st4(g1t, k1t); st4(g1x, k1x); st4(g1y, k1y);
-            if (MODEL == MODEL_IC) { st4(g2t, k2t); st4(g2x, k2x); st4(g2y, k2y); }
+            st4m(g1t, k1t, nv); st4m(g1x, k1x, nv); st4m(g1y, k1y, nv);
+            if (MODEL == MODEL_IC) { st4m(g2t, k2t, nv); st4m(g2x, k2x, nv); st4m(g2y, k2y, nv); }
         } else if (MODE == MODE_STEPS) {
-            st4(g1t, sg1);
-            st4(g2t, sg2);
+            st4m(g1t, sg1, nv);
+            st4m(g2t, sg2, nv);
         } else if (MODE == MODE_ENERGY) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (i >= nv) continue;
                 diag[0] += k1t[i] * k1t[i] + k1x[i] * k1x[i] + k1y[i] * k1y[i] + k2t[i] * k2t[i] + k2x[i] * k2x[i] + k2y[i] * k2y[i];
                 if (MODEL == MODEL_IC) {
                     part[0] += g.radius1 * sqrtf(k1t[i] * k1t[i] + k1x[i] * k1x[i] + k1y[i] * k1y[i]) +
@@ -1042,6 +727,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
                 ld4(x0u, a.u0 + j); ld4(x0w, a.w0 + j);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    if (i >= nv) continue;
                     diag[0] += uc[i] * uc[i] + wc[i] * wc[i];
                     diag[1] += (uc[i] - x0u[i]) * (uc[i] - x0u[i]) + (wc[i] - x0w[i]) * (wc[i] - x0w[i]);
                 }
@@ -1065,14 +751,14 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
                     const float sc = ball_scale(n1t[i] * n1t[i] + n1x[i] * n1x[i] + n1y[i] * n1y[i], g.radius1);
                     n1t[i] *= sc; n1x[i] *= sc; n1y[i] *= sc;
                 }
-                if (REDUCE) {
+                if (REDUCE && i < nv) {
                     part[0] += (n1t[i] - o1t[i]) * (n1t[i] - o1t[i]) + (n1x[i] - o1x[i]) * (n1x[i] - o1x[i]) +
                                (n1y[i] - o1y[i]) * (n1y[i] - o1y[i]);
                     part[1] += n1t[i] * n1t[i] + n1x[i] * n1x[i] + n1y[i] * n1y[i];
                 }
             }
-            if (pex || !MMC_SKIP_NOPAIR) st4(g1t, n1t);
-            st4(g1x, n1x); st4(g1y, n1y);
+            if (pex || !MMC_SKIP_NOPAIR) st4m(g1t, n1t, nv);
+            st4m(g1x, n1x, nv); st4m(g1y, n1y, nv);
             if (MODEL == MODEL_IC) {
                 float n2t[4], n2x[4], n2y[4];
 #pragma unroll
@@ -1082,14 +768,14 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
                     n2y[i] = o2y[i] + sg2[i] * k2y[i];
                     const float sc = ball_scale(n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i], g.radius2);
                     n2t[i] *= sc; n2x[i] *= sc; n2y[i] *= sc;
-                    if (REDUCE) {
+                    if (REDUCE && i < nv) {
                         part[0] += (n2t[i] - o2t[i]) * (n2t[i] - o2t[i]) + (n2x[i] - o2x[i]) * (n2x[i] - o2x[i]) +
                                    (n2y[i] - o2y[i]) * (n2y[i] - o2y[i]);
                         part[1] += n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i];
                     }
                 }
-                if (pex || !MMC_SKIP_NOPAIR) st4(g2t, n2t);
-                st4(g2x, n2x); st4(g2y, n2y);
+                if (pex || !MMC_SKIP_NOPAIR) st4m(g2t, n2t, nv);
+                st4m(g2x, n2x, nv); st4m(g2y, n2y, nv);
                 if (g.fixed && g.frame_begin + t == 0) {
                     // q <- q + (xbar - x0): F*(q) = <x0, q>, identity rows, step 1 (:560-564)
                     float q1o[4], q2o[4], x0u[4], x0w[4], q1n[4], q2n[4];
@@ -1098,12 +784,12 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_DUAL) void k_dual4(Geom g, Arr
                     for (int i = 0; i < 4; ++i) {
                         q1n[i] = q1o[i] + (uc[i] - x0u[i]);
                         q2n[i] = q2o[i] + (wc[i] - x0w[i]);
-                        if (REDUCE) {
+                        if (REDUCE && i < nv) {
                             part[0] += (q1n[i] - q1o[i]) * (q1n[i] - q1o[i]) + (q2n[i] - q2o[i]) * (q2n[i] - q2o[i]);
                             part[1] += q1n[i] * q1n[i] + q2n[i] * q2n[i];
                         }
                     }
-                    st4(a.q1 + j, q1n); st4(a.q2 + j, q2n);
+                    st4m(a.q1 + j, q1n, nv); st4m(a.q2 + j, q2n, nv);
                 }
             }
         }
@@ -1406,29 +1092,30 @@ __global__ __launch_bounds__(MMC_THREADS) void k_init_finalize(Geom g, Arrays a,
     const int j = blockIdx.x * MMC_THREADS + threadIdx.x;
     if (j >= g.N) return;
     const int r = j % g.Ny, c = j / g.Ny;
-    float s = from_fx(tmp[j]);
-    if (pair_exists(g, t) && pair_is_IF(g, t) && make_taps(g, r, c, FR(a.vx, t)[j], FR(a.vy, t)[j]).valid) s += 1.f;
+    int nid = 0;
+    if (pair_exists(g, t) && pair_is_IF(g, t) && make_taps(g, r, c, FR(a.vx, t)[j], FR(a.vy, t)[j]).valid) ++nid;
     if (pair_exists(g, t - 1) && !pair_is_IF(g, t - 1) &&
-        make_taps(g, r, c, FR(a.vx, t - 1)[j], FR(a.vy, t - 1)[j]).valid) s += 1.f;
-    FR(a.cW, t)[j] = s;
+        make_taps(g, r, c, FR(a.vx, t - 1)[j], FR(a.vy, t - 1)[j]).valid) ++nid;
+    FR(a.cW, t)[j] = from_fx_plus(tmp[j], nid);
 }
 
 // Per row quad of frame t: how many unmasked -Id entries of W sit in each of its four columns
 // of the operator (0, 1 or 2), two bits per row.  With the scattered tap weights this is cW.
 __global__ __launch_bounds__(MMC_THREADS) void k_init_idq(Geom g, Arrays a, int t) {
     const int qi = blockIdx.x * MMC_THREADS + threadIdx.x;
-    if (qi >= g.N / 4) return;
-    const int j = 4 * qi, r = j % g.Ny, c = j / g.Ny;
+    const int qpc = (g.Ny + 3) >> 2;                    // quads per column; the last one may be short
+    if (qi >= qpc * g.Nx) return;
+    const int c = qi / qpc, r = 4 * (qi - c * qpc), j = r + g.Ny * c;
     const bool useA = pair_exists(g, t) && pair_is_IF(g, t);
     const bool useB = pair_exists(g, t - 1) && !pair_is_IF(g, t - 1);
     unsigned bits = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 && r + i < g.Ny; ++i) {
         unsigned n = 0;
         if (useA && make_taps(g, r + i, c, FR(a.vx, t)[j + i], FR(a.vy, t)[j + i]).valid) ++n;
         if (useB && make_taps(g, r + i, c, FR(a.vx, t - 1)[j + i], FR(a.vy, t - 1)[j + i]).valid) ++n;
         bits |= n << (2 * i);
     }
-    a.idq[(size_t)t * (g.N / 4 + 1) + qi] = (uint8_t)bits;
+    a.idq[(size_t)t * MMC_IDQ_PER_FRAME(g) + qi] = (uint8_t)bits;
 }
 
 // Per (pair, tile): the rows and columns of the warped frame that the dual sweep stages in LDS for
@@ -1625,7 +1312,7 @@ __global__ __launch_bounds__(MMC_THREADS) void k_stream_probe(Geom g, ProbePlane
 }
 
 // One launch of the probe over local frames [0, nf): the dual-like pass walks the block sequence
-// backwards like the dual sweep, the primal-like one forwards.  Needs Ny % 4 == 0 and planes of at
+// backwards like the dual sweep, the primal-like one forwards.  Needs Ny % 4 == 0 (mmc_create probes only such blocks) and planes of at
 // least nf + 2 frames.
 hipError_t mmc_launch_stream_probe(const Geom &g0, float *const planes[12], int nf, bool dual_like, hipStream_t s) {
     Geom g = g0;
@@ -1641,17 +1328,6 @@ hipError_t mmc_launch_stream_probe(const Geom &g0, float *const planes[12], int 
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
-
-template <int MODEL>
-static void launch_primal_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
-    dim3 grid(g.ntiles, nf), block(MMC_THREADS);
-    if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal<MODEL, MODE_RAW, false>), grid, block, 0, s, g, a, t0);
-    else if (mode == MODE_DUALOBJ) hipLaunchKernelGGL((k_primal<MODEL, MODE_DUALOBJ, false>), grid, block, 0, s, g, a, t0);
-    else if (mode == MODE_STEPS || mode == MODE_STEPS_UPD)      // the scalar kernel always reads the cW plane
-        hipLaunchKernelGGL((k_primal<MODEL, MODE_STEPS, false>), grid, block, 0, s, g, a, t0);
-    else if (reduce) hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, true>), grid, block, 0, s, g, a, t0);
-    else hipLaunchKernelGGL((k_primal<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
-}
 
 // -DMMC_TUNE_LDS_PAD: env MMC_LDS_PAD = bytes of unused LDS added to every sweep launch, which lowers the
 // number of workgroups a CU holds (occupancy experiments); a regular build adds nothing.
@@ -1697,25 +1373,9 @@ hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int
         const int total = a.net * (t1 - t0);
         hipLaunchKernelGGL(k_corr_u, dim3((total + MMC_THREADS - 1) / MMC_THREADS), dim3(MMC_THREADS), 0, s, g, a, t0, t1 - t0);
     }
-    if (g.Ny % 4 == 0) {   // row-quad kernels need 16-byte aligned columns
-        if (g.f == 4) launch_primal4<4>(g, a, t0, t1 - t0, mode, reduce, s);
-        else launch_primal4<0>(g, a, t0, t1 - t0, mode, reduce, s);
-        return hipGetLastError();
-    }
-    if (g.model == MODEL_IC) launch_primal_m<MODEL_IC>(g, a, t0, t1 - t0, mode, reduce, s);
-    else if (g.model == MODEL_K1) launch_primal_m<MODEL_K1>(g, a, t0, t1 - t0, mode, reduce, s);
-    else launch_primal_m<MODEL_ADD>(g, a, t0, t1 - t0, mode, reduce, s);
+    if (g.f == 4) launch_primal4<4>(g, a, t0, t1 - t0, mode, reduce, s);
+    else launch_primal4<0>(g, a, t0, t1 - t0, mode, reduce, s);
     return hipGetLastError();
-}
-
-template <int MODEL>
-static void launch_dual_m(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
-    dim3 grid(g.ntiles, nf), block(MMC_THREADS);
-    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual<MODEL, MODE_RAW, false>), grid, block, 0, s, g, a, t0);
-    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual<MODEL, MODE_STEPS, false>), grid, block, 0, s, g, a, t0);
-    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual<MODEL, MODE_ENERGY, false>), grid, block, 0, s, g, a, t0);
-    else if (reduce) hipLaunchKernelGGL((k_dual<MODEL, MODE_UPDATE, true>), grid, block, 0, s, g, a, t0);
-    else hipLaunchKernelGGL((k_dual<MODEL, MODE_UPDATE, false>), grid, block, 0, s, g, a, t0);
 }
 
 template <int MODEL, int F>
@@ -1748,22 +1408,9 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
         const int total = a.ne * nf;
         hipLaunchKernelGGL(k_corr_p, dim3((total + MMC_THREADS - 1) / MMC_THREADS), dim3(MMC_THREADS), 0, s, g, a, t0, nf);
     }
-    if (g.Ny % 4 == 0 && !ABL(16)) {
-        // fused row-quad kernel: regulariser duals and data-term dual in one launch
-        if (g.f == 4) launch_dual4<4>(g, a, t0, nf, mode, reduce, s);
-        else launch_dual4<0>(g, a, t0, nf, mode, reduce, s);
-        return hipGetLastError();
-    }
-    if (g.model == MODEL_IC) launch_dual_m<MODEL_IC>(g, a, t0, nf, mode, reduce, s);
-    else if (g.model == MODEL_K1) launch_dual_m<MODEL_K1>(g, a, t0, nf, mode, reduce, s);
-    else launch_dual_m<MODEL_ADD>(g, a, t0, nf, mode, reduce, s);
-    const size_t total = (size_t)g.n * nf;
-    dim3 gridp((unsigned)((total + MMC_THREADS - 1) / MMC_THREADS)), block(MMC_THREADS);
-    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual_p<MODE_RAW, false>), gridp, block, 0, s, g, a, t0, nf);
-    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual_p<MODE_STEPS, false>), gridp, block, 0, s, g, a, t0, nf);
-    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual_p<MODE_ENERGY, false>), gridp, block, 0, s, g, a, t0, nf);
-    else if (reduce) hipLaunchKernelGGL((k_dual_p<MODE_UPDATE, true>), gridp, block, 0, s, g, a, t0, nf);
-    else hipLaunchKernelGGL((k_dual_p<MODE_UPDATE, false>), gridp, block, 0, s, g, a, t0, nf);
+    // regulariser duals and data-term dual in one launch
+    if (g.f == 4) launch_dual4<4>(g, a, t0, nf, mode, reduce, s);
+    else launch_dual4<0>(g, a, t0, nf, mode, reduce, s);
     return hipGetLastError();
 }
 
@@ -1789,8 +1436,7 @@ hipError_t mmc_launch_init_warp(const Geom &g, const Arrays &a, void *frame_word
             if (tf == t) hipLaunchKernelGGL(k_init_scatter, grid, block, 0, s, g, a, q, tmp);
         });
         hipLaunchKernelGGL(k_init_finalize, grid, block, 0, s, g, a, t, tmp);
-        if (g.Ny % 4 == 0)
-            hipLaunchKernelGGL(k_init_idq, dim3((g.N / 4 + MMC_THREADS - 1) / MMC_THREADS), block, 0, s, g, a, t);
+        hipLaunchKernelGGL(k_init_idq, dim3((unsigned)((MMC_IDQ_PER_FRAME(g) + MMC_THREADS - 1) / MMC_THREADS)), block, 0, s, g, a, t);
     }
     for_each_scattering_pair(g, [&](int, int q) { hipLaunchKernelGGL(k_init_srcbox, grid, block, 0, s, g, a, q); });
     hipLaunchKernelGGL(k_init_tapbox, dim3(g.ntiles, g.L), block, 0, s, g, a);

@@ -1,6 +1,6 @@
 """The diagnostics of mmc_stats (primal and dual objective, gap, optimality residuals) against the oracle's
 model-level definitions (oracle.primal_energy / dual_terms / optimality_residuals) at equal iteration
-counts, for every model, for the kernels outside the row-quad form, for a pinned first frame and for a
+counts, for every model, for row counts that are not multiples of 4, for a pinned first frame and for a
 sequence cut into blocks; and the stopping test built on them."""
 import numpy as np
 import pytest

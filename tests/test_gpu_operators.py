@@ -129,7 +129,7 @@ def test_h_matches_oracle():
 @pytest.mark.parametrize("factor,ny,nx", [(3, 5, 6), (2, 6, 9), (1, 12, 8), (8, 3, 2)])
 def test_other_zoom_factors(factor, ny, nx):
     """'stride' sampling at zoom factors other than 4: factor 3 gives a row count that is
-    not a multiple of 4 (scalar kernels), 2 / 1 / 8 the generic-factor row-quad kernels."""
+    not a multiple of 4 (short last row quads), 2 / 1 / 8 other lane groupings of the data term."""
     f, v, _ = make_case(9, ny, nx, 3, factor=factor)
     k = orc.fspecial_gaussian(5, 1.0)
     P = orc.build_problem(f, v, factor=factor, k=k, interpMethod="stride")

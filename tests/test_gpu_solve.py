@@ -141,8 +141,9 @@ def test_motion_boundary_inside_tiles():
 
 @pytest.mark.parametrize("factor,ny,nx", [(2, 14, 18), (3, 7, 8)])
 def test_solve_parity_other_zoom_factors(factor, ny, nx):
-    """Update sweeps of the generic-factor row-quad kernels (zoom 2) and of the scalar kernels
-    (zoom 3: the row count is not a multiple of 4), 'stride' sampling with a 5x5 blur."""
+    """Update sweeps for zoom factors other than 4: zoom 2, and zoom 3, which does not divide the tile
+    and here gives a row count that is not a multiple of 4 (short last row quads); 'stride' sampling
+    with a 5x5 blur."""
     from superresolution_amd.solver import FrameBlockSolver
     f, v, _ = make_case(33, ny, nx, 3, factor=factor, flow="smooth", flow_scale=1.5)
     k = orc.fspecial_gaussian(5, 1.0)

@@ -1,5 +1,5 @@
 """Iteration time of the code paths beside the headline one, on 1080p-sized frames (10 frames each): other
-zoom factors, a row count that is not a multiple of 4 (sweeps outside the row-quad form), samplers
+zoom factors, a row count that is not a multiple of 4 (short last row quads, unaligned columns), samplers
 handed over as rows.  usage: python tools/bench_paths.py [iters]"""
 import os
 import sys

@@ -2,7 +2,7 @@
 # tools/build_variant.sh NAME [-DFLAG ...]: experimental build of the library into
 # superresolution_amd/lib/variants/libmmc_NAME.so (select it with MMC_HIP_LIB=...).
 # -DMMC_ABLATION compiles in the MMC_DEBUG switches (bit mask: 1 no scatter, 2 no scatter atomics, 4 no A'p,
-# 16 unfused dual sweep, 32 plain block order, 128 cA from memory, 256 no warp taps, 512 no data term,
+# 32 plain block order, 128 cA from memory, 256 no warp taps, 512 no data term,
 # 1024 taps gathered from global memory, 2048 / 4096 generic A'p / data-term paths).
 set -e
 name=$1; shift
