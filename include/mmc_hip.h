@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MMC_ABI_VERSION 3
+#define MMC_ABI_VERSION 4
 
 typedef enum mmc_status {
     MMC_OK = 0,
@@ -108,6 +108,7 @@ typedef struct mmc_stats {
     double solve_seconds;      /* host wall time of the call, device-synchronised      */
     double primal_energy, dual_energy, gap, dual_infeasibility;
     double opt_res_primal, opt_res_dual, norm_KTy, norm_Kx;
+    double step_balance;       /* s of mmc_set_step_balance at the end of the call     */
 } mmc_stats;
 
 /* Raw sums behind the diagnostics of mmc_stats, for adding up over frame blocks:
@@ -303,6 +304,28 @@ int mmc_state_halo_info(mmc_handle *h, mmc_halo *out);
 int mmc_problem_size(const mmc_handle *h, double *n_primal, double *n_dual);
 int mmc_stats_from_diag(const double diag[MMC_NUM_DIAG], double n_primal, double n_dual, float tol, mmc_stats *st);
 
+/* Step balance.  The step sizes are the diagonal preconditioners T_j = 1 / sum_i |K_ij| and
+ * S_i = 1 / sum_j |K_ij| with tau0 = sigma0 = 1 (MultiframeMotionCoupling.m:349-351); the reference
+ * hands those start values to prost's adaptive rule ('stepsize','boyd'), which then moves weight
+ * between the primal and the dual steps.  mmc_set_step_balance applies one global factor s > 0:
+ * every tau is multiplied by s and every sigma divided by it, which keeps tau * sigma and with it
+ * the convergence condition of the preconditioned iteration.  s = 1 is the default and the setting
+ * of every fixed-iteration comparison with the oracle.  mmc_set_step_adaptation(h, 1) lets mmc_solve
+ * choose s itself by residual balancing: every 50 iterations it compares the step-weighted changes
+ * P = ||(x+ - x) / tau|| and D = ||(y+ - y) / sigma|| and, with Delta = 1.5, alpha = 0.5 at first
+ * and alpha <- 0.95 alpha after every change, sets s <- s / (1 - alpha) when P > Delta D and
+ * s <- s (1 - alpha) when P < D / Delta (mmc_step_balance_rule; the rule of adaptive PDHG, of which
+ * prost's 'boyd' setting is an instance whose constants live in the absent prost submodule: own
+ * definition, not a reproduction).  A block driven sweep by sweep reads its share of P^2 and D^2 with
+ * mmc_step_sums_read after sweeps with reduce != 0, adds them over the blocks and applies the rule
+ * to every block.  Takes effect at the next sweep; no mmc_init needed. */
+int mmc_set_step_balance(mmc_handle *h, float s);
+int mmc_get_step_balance(const mmc_handle *h, float *s);
+int mmc_set_step_adaptation(mmc_handle *h, int enable);
+int mmc_step_sums_read(mmc_handle *h, double out[2]);           /* synchronises */
+/* The rule above as a function: sums = {P^2, D^2}; updates *balance and *alpha; returns 1 if it changed them */
+int mmc_step_balance_rule(const double sums[2], double *balance, double *alpha);
+
 /* Per-kernel timing of mmc_solve with HIP events recorded on the library's
  * stream around every launch (the reference only has tic/toc around run,
  * testfile.m:66-68).  With profiling enabled the next mmc_solve times up to
@@ -373,6 +396,9 @@ int mmc_group_solve(mmc_group *g, int max_iters, float tol, int check_every,
 int mmc_group_get_state(mmc_group *g, float *u, float *w);
 /* mmc_set_diagnostics for every block of the group */
 int mmc_group_set_diagnostics(mmc_group *g, int mode);
+/* mmc_set_step_balance / mmc_set_step_adaptation for the whole sequence (one s for all blocks) */
+int mmc_group_set_step_balance(mmc_group *g, float s);
+int mmc_group_set_step_adaptation(mmc_group *g, int enable);
 
 /* ---- Test hooks: the operators of the sweeps without the prox maps. ---------
  * K x for x = (u, w): out_p is n*L, out_g1/out_g2 are component-major

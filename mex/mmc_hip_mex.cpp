@@ -9,7 +9,8 @@
 // the gateway always works on a group (include/mmc_hip.h): S.devices = [0 1 ... 7]
 // spreads the sequence over the GPUs of the node, one frame block per entry; without
 // that field it is one block on S.device.  Commands (first argument):
-//   h = mmc_hip_mex('create', S)      S: struct with the fields of mmc_params (+ devices)
+//   h = mmc_hip_mex('create', S)      S: struct with the fields of mmc_params (+ devices; + step_balance: a positive
+//                                     factor, or adapt_steps = 1 for the library's residual balancing)
 //   mmc_hip_mex('lowres', h, f)       f: ny x nx x nc double
 //   mmc_hip_mex('blur',   h, k)       k: odd x odd double, or []
 //   mmc_hip_mex('sampling', h, Sy, Sx) 1-D factors of samplingOperator, ny x Ny and nx x Nx
@@ -143,6 +144,9 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         if (p.nc_global > 0 && (int)devs.size() > p.nc_global) devs.resize((size_t)p.nc_global);
         Entry e{nullptr, p};
         check(mmc_group_create(&p, devs.empty() ? 1 : (int)devs.size(), devs.empty() ? nullptr : devs.data(), &e.g), nullptr);
+        const double bal = field(s, "step_balance", 1.0);
+        if (bal != 1.0) check(mmc_group_set_step_balance(e.g, (float)bal), e.g);
+        if (field(s, "adapt_steps", 0.0) != 0.0) check(mmc_group_set_step_adaptation(e.g, 1), e.g);
         g_handles[g_next] = e;
         if (!mexIsLocked()) mexLock();
         plhs[0] = mxCreateDoubleScalar((double)g_next++);
@@ -247,8 +251,9 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         if (nlhs > 1) plhs[1] = has_w ? to_double(w, Ny, Nx, nc) : mxCreateDoubleMatrix(0, 0, mxREAL);
         if (nlhs > 2) {
             const char *names[] = {"iterations", "converged", "res_primal", "res_dual", "seconds", "primal_energy", "dual_energy",
-                                   "gap", "dual_infeasibility", "opt_res_primal", "opt_res_dual"};
-            plhs[2] = mxCreateStructMatrix(1, 1, 11, names);
+                                   "gap", "dual_infeasibility", "opt_res_primal", "opt_res_dual", "step_balance"};
+            plhs[2] = mxCreateStructMatrix(1, 1, 12, names);
+            mxSetField(plhs[2], 0, "step_balance", mxCreateDoubleScalar(st.step_balance));
             mxSetField(plhs[2], 0, "primal_energy", mxCreateDoubleScalar(st.primal_energy));
             mxSetField(plhs[2], 0, "dual_energy", mxCreateDoubleScalar(st.dual_energy));
             mxSetField(plhs[2], 0, "gap", mxCreateDoubleScalar(st.gap));

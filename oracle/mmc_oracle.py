@@ -598,16 +598,39 @@ def prox_Fstar(P, y, S):
     return out
 
 
-def pdhg(P, iters, x=None, y=None, dtype=np.float64, callback=None):
+STEP_ADAPT_EVERY, STEP_DELTA, STEP_ETA = 50, 1.5, 0.95
+
+
+def step_balance_rule(P2, D2, balance, alpha):
+    """Residual balancing of the step sizes (the rule of adaptive PDHG; prost's 'stepsize','boyd' setting,
+    MultiframeMotionCoupling.m:349-351, is of this family, its constants live in the absent submodule):
+    P2 = ||(x+ - x)/tau||^2, D2 = ||(y+ - y)/sigma||^2.  Returns the new (balance, alpha)."""
+    Pn, Dn = np.sqrt(max(P2, 0.0)), np.sqrt(max(D2, 0.0))
+    if not (Pn > 0 and Dn > 0 and np.isfinite(Pn) and np.isfinite(Dn)):
+        return balance, alpha
+    if Pn > STEP_DELTA * Dn:
+        return min(max(balance / (1.0 - alpha), 1e-4), 1e4), alpha * STEP_ETA
+    if Pn < Dn / STEP_DELTA:
+        return min(max(balance * (1.0 - alpha), 1e-4), 1e4), alpha * STEP_ETA
+    return balance, alpha
+
+
+def pdhg(P, iters, x=None, y=None, dtype=np.float64, callback=None, balance=1.0, adapt=False, trace=None):
     """DECISION (iteration): preconditioned PDHG, primal step first:
         x+ = prox_G(x - T .* K'y);  xb = 2 x+ - x;  y+ = prox_F*(y + S .* K xb)
     run for a fixed number of iterations.  Returns (x, y, last_change) where
     last_change = (||x+ - x||, ||x+||, ||y+ - y||, ||y+||) of the final step.
+    balance: one global factor s, T <- s T and S <- S / s (the product of the steps is unchanged).
+    adapt: every STEP_ADAPT_EVERY iterations s is moved by step_balance_rule; trace (a list) receives
+    (iteration, s, P2, D2) at those points.
     """
     K = P.K.astype(dtype)
     KT = P.KT.astype(dtype)
-    T = P.T.astype(dtype)
-    S = P.S.astype(dtype)
+    T0 = P.T.astype(dtype)
+    S0 = P.S.astype(dtype)
+    s_bal, alpha = float(balance), 0.5
+    T = (T0 * dtype(s_bal)).astype(dtype)
+    S = (S0 / dtype(s_bal)).astype(dtype)
     x = (P.x0 if x is None else x).astype(dtype)
     y = (P.y0 if y is None else y).astype(dtype)
     Pd = P
@@ -624,6 +647,14 @@ def pdhg(P, iters, x=None, y=None, dtype=np.float64, callback=None):
         if it == iters - 1 or callback is not None:
             chg = (float(np.linalg.norm(xn - x)), float(np.linalg.norm(xn)),
                    float(np.linalg.norm(yn - y)), float(np.linalg.norm(yn)))
+        if adapt and (it + 1) % STEP_ADAPT_EVERY == 0:
+            P2 = float((((xn - x) / T).astype(np.float64) ** 2).sum())
+            D2 = float((((yn - y) / S).astype(np.float64) ** 2).sum())
+            s_bal, alpha = step_balance_rule(P2, D2, s_bal, alpha)
+            if trace is not None:
+                trace.append((it + 1, s_bal, P2, D2))
+            T = (T0 * dtype(s_bal)).astype(dtype)
+            S = (S0 / dtype(s_bal)).astype(dtype)
         x, y = xn, yn
         if callback is not None:
             callback(it, x, y, chg)

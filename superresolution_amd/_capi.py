@@ -12,7 +12,7 @@ import numpy as np
 
 from .build import LIB_PATH
 
-MMC_ABI_VERSION = 3
+MMC_ABI_VERSION = 4
 MMC_NUM_SUMS = 4
 MMC_NUM_DIAG = 9
 DIAG_OFF, DIAG_AUTO, DIAG_ALWAYS = 0, 1, 2
@@ -53,7 +53,7 @@ class mmc_stats(C.Structure):
                 ("res_primal", C.c_double), ("res_dual", C.c_double), ("solve_seconds", C.c_double),
                 ("primal_energy", C.c_double), ("dual_energy", C.c_double), ("gap", C.c_double),
                 ("dual_infeasibility", C.c_double), ("opt_res_primal", C.c_double), ("opt_res_dual", C.c_double),
-                ("norm_KTy", C.c_double), ("norm_Kx", C.c_double)]
+                ("norm_KTy", C.c_double), ("norm_Kx", C.c_double), ("step_balance", C.c_double)]
 
     def as_dict(self):
         """Every field; the diagnostics group is NaN when it was not evaluated."""
@@ -111,6 +111,13 @@ SIGNATURES = {
     "mmc_problem_size": (C.c_int, [_H, _dp, _dp]),
     "mmc_stats_from_diag": (C.c_int, [_dp, C.c_double, C.c_double, C.c_float, C.POINTER(mmc_stats)]),
     "mmc_group_set_diagnostics": (C.c_int, [_H, C.c_int]),
+    "mmc_set_step_balance": (C.c_int, [_H, C.c_float]),
+    "mmc_get_step_balance": (C.c_int, [_H, _fp]),
+    "mmc_set_step_adaptation": (C.c_int, [_H, C.c_int]),
+    "mmc_step_sums_read": (C.c_int, [_H, _dp]),
+    "mmc_step_balance_rule": (C.c_int, [_dp, _dp, _dp]),
+    "mmc_group_set_step_balance": (C.c_int, [_H, C.c_float]),
+    "mmc_group_set_step_adaptation": (C.c_int, [_H, C.c_int]),
     "mmc_set_profiling": (C.c_int, [_H, C.c_int]),
     "mmc_get_profile": (C.c_int, [_H, _dp, C.POINTER(C.c_int)]),
     "mmc_get_sweep_profile": (C.c_int, [_H, _dp, C.POINTER(C.c_int)]),

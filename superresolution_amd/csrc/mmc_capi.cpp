@@ -45,6 +45,9 @@ struct mmc_handle {
     bool geometry_only = false;              // no per-pixel state (mmc_internal_create_geometry)
     size_t plane_skew = 0;                   // bytes between the starts of consecutive per-pixel planes modulo their allocation alignment
     int diagnostics = MMC_DIAG_AUTO;         // when the second group of mmc_stats is evaluated
+    double balance = 1.0;                    // step balance s: tau * s, sigma / s
+    bool adapt = false;                      // mmc_solve chooses s by residual balancing
+    double adapt_alpha = 0.5;
     bool profiling = false;
     std::vector<hipEvent_t> events;       // 4 per profiled iteration
     double prof_ms[3] = {0, 0, 0};
@@ -365,6 +368,7 @@ static int create_handle(const mmc_params *p, bool geometry_only, mmc_handle **o
     }
     g.inv_h = 1.f;
     g.wsgn = -1.f;
+    g.tau_s = g.sigma_s = 1.f;
 #ifdef MMC_ABLATION
     if (const char *e = getenv("MMC_DEBUG")) g.dbg = atoi(e);
 #endif
@@ -1146,6 +1150,45 @@ extern "C" int mmc_halo_info(mmc_handle *h, mmc_halo *out) {
     return MMC_OK;
 }
 
+// ---- step balance -------------------------------------------------------------------------------
+enum { STEP_ADAPT_EVERY = 50 };
+
+extern "C" int mmc_set_step_balance(mmc_handle *h, float s) {
+    REQUIRE_HANDLE(h);
+    if (!(s > 0.f) || !std::isfinite(s)) return fail(h, MMC_ERR_INVALID_ARG, "mmc_set_step_balance: the factor must be positive and finite");
+    h->balance = (double)s;
+    h->g.tau_s = s;
+    h->g.sigma_s = 1.f / s;
+    return MMC_OK;
+}
+
+extern "C" int mmc_get_step_balance(const mmc_handle *h, float *s) {
+    if (!h || !s) return MMC_ERR_INVALID_ARG;
+    *s = (float)h->balance;
+    return MMC_OK;
+}
+
+extern "C" int mmc_set_step_adaptation(mmc_handle *h, int enable) {
+    REQUIRE_HANDLE(h);
+    h->adapt = enable != 0;
+    h->adapt_alpha = 0.5;
+    return MMC_OK;
+}
+
+extern "C" int mmc_step_balance_rule(const double sums[2], double *balance, double *alpha) {
+    if (!sums || !balance || !alpha) return 0;
+    const double Delta = 1.5, eta = 0.95;
+    const double P = std::sqrt(std::max(sums[0], 0.0)), D = std::sqrt(std::max(sums[1], 0.0));
+    if (!(P > 0.0) || !(D > 0.0) || !std::isfinite(P) || !std::isfinite(D)) return 0;
+    double s = *balance;
+    if (P > Delta * D) s /= (1.0 - *alpha);
+    else if (P < D / Delta) s *= (1.0 - *alpha);
+    else return 0;
+    *balance = std::min(std::max(s, 1e-4), 1e4);
+    *alpha *= eta;
+    return 1;
+}
+
 // ---- diagnostics: primal and dual objective, gap, optimality residuals -------------------------
 
 extern "C" int mmc_set_diagnostics(mmc_handle *h, int mode) {
@@ -1227,6 +1270,13 @@ static bool diag_wanted(const mmc_handle *h, float tol, mmc_progress_cb cb) {
     return h->diagnostics == MMC_DIAG_ALWAYS || (h->diagnostics == MMC_DIAG_AUTO && (tol > 0.f || cb));
 }
 
+extern "C" int mmc_step_sums_read(mmc_handle *h, double out[2]) {
+    REQUIRE_HANDLE(h);
+    if (!out) return fail(h, MMC_ERR_INVALID_ARG, "mmc_step_sums_read: null output");
+    int rc = use_device(h); if (rc) return rc;
+    return read_sums(h, SUM_WRES, 2, out);
+}
+
 static void fill_stats(mmc_stats *st, const double s[MMC_NUM_SUMS]) {
     const double tiny = 1e-30;
     st->res_primal = std::sqrt(s[0]) / std::max(std::sqrt(s[1]), tiny);
@@ -1261,17 +1311,29 @@ extern "C" int mmc_solve(mmc_handle *h, int max_iters, float tol, int check_ever
             h->events.push_back(e);
         }
     }
+    st.step_balance = h->balance;
     for (int it = 0; it < max_iters; ++it) {
         const bool check = ((it + 1) % check_every == 0) || it == max_iters - 1;
-        if (check && (rc = zero_sums(h))) return rc;
+        const bool adapt_now = h->adapt && (it + 1) % STEP_ADAPT_EVERY == 0;
+        const bool reduce = check || adapt_now;
+        if (reduce && (rc = zero_sums(h))) return rc;
         const bool prof = h->profiling && it < PROF_MAX_ITERS;
         hipEvent_t *ev = prof ? &h->events[(size_t)2 * it] : nullptr;
         if (prof && it == 0) HIPCHK(h, hipEventRecord(ev[0], h->stream));
-        HIPCHK(h, mmc_launch_primal(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream));
+        HIPCHK(h, mmc_launch_primal(g, h->a, 0, h->L, MODE_UPDATE, reduce, h->stream));
         if (prof) HIPCHK(h, hipEventRecord(ev[1], h->stream));
-        HIPCHK(h, mmc_launch_dual(g, h->a, 0, h->L, MODE_UPDATE, check, h->stream));
+        HIPCHK(h, mmc_launch_dual(g, h->a, 0, h->L, MODE_UPDATE, reduce, h->stream));
         if (prof) { HIPCHK(h, hipEventRecord(ev[2], h->stream)); prof_n = it + 1; }
         st.iterations = it + 1;
+        if (adapt_now) {
+            double ws[2];
+            if ((rc = read_sums(h, SUM_WRES, 2, ws))) return rc;
+            if (mmc_step_balance_rule(ws, &h->balance, &h->adapt_alpha)) {
+                h->g.tau_s = (float)h->balance;
+                h->g.sigma_s = (float)(1.0 / h->balance);
+            }
+            st.step_balance = h->balance;
+        }
         if (check) {
             double s[MMC_NUM_SUMS];
             if ((rc = read_sums(h, 0, MMC_NUM_SUMS, s))) return rc;

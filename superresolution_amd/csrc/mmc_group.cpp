@@ -41,6 +41,9 @@ struct mmc_group {
     float h = 0.f;
     bool have_h = false;
     int diagnostics = MMC_DIAG_AUTO;
+    double balance = 1.0;         // step balance of every block (mmc_set_step_balance)
+    bool adapt = false;           // mmc_group_solve chooses it by residual balancing
+    double adapt_alpha = 0.5;
     std::string err;
 };
 
@@ -271,6 +274,22 @@ static int group_diagnostics(mmc_group *g, float tol, mmc_stats *st, bool *stop)
     return MMC_OK;
 }
 
+extern "C" int mmc_group_set_step_balance(mmc_group *g, float s) {
+    REQUIRE_GROUP(g);
+    for (GroupBlock &b : g->blocks) GBLK(g, b, mmc_set_step_balance(b.h, s));
+    g->balance = (double)s;
+    return MMC_OK;
+}
+
+extern "C" int mmc_group_set_step_adaptation(mmc_group *g, int enable) {
+    REQUIRE_GROUP(g);
+    g->adapt = enable != 0;
+    g->adapt_alpha = 0.5;
+    // a one-block group hands the whole solve to mmc_solve
+    if (g->blocks.size() == 1) GBLK(g, g->blocks[0], mmc_set_step_adaptation(g->blocks[0].h, enable));
+    return MMC_OK;
+}
+
 extern "C" int mmc_group_set_diagnostics(mmc_group *g, int mode) {
     REQUIRE_GROUP(g);
     for (GroupBlock &b : g->blocks) GBLK(g, b, mmc_set_diagnostics(b.h, mode));
@@ -366,8 +385,11 @@ extern "C" int mmc_group_solve(mmc_group *g, int max_iters, float tol, int check
     }
     for (GroupBlock &b : B) GBLK(g, b, mmc_sync(b.h));
     const auto t_start = std::chrono::steady_clock::now();
+    st.step_balance = g->balance;
     for (int it = 0; it < max_iters; ++it) {
-        const bool check = ((it + 1) % check_every == 0) || it == max_iters - 1;
+        const bool want_check = ((it + 1) % check_every == 0) || it == max_iters - 1;
+        const bool adapt_now = g->adapt && (it + 1) % 50 == 0;
+        const bool check = want_check || adapt_now;          // sweeps with reduced sums
         if (check) for (GroupBlock &b : B) GBLK(g, b, mmc_sums_reset(b.h));
         // primal sweep: a block's first frame needs the previous block's temporal duals, and its
         // xbar may only be overwritten once the copy of the last iteration has read it
@@ -422,7 +444,18 @@ extern "C" int mmc_group_solve(mmc_group *g, int max_iters, float tol, int check
             GHIP(g, hipEventRecord(b.duals_sent, b.copy));
         }
         st.iterations = it + 1;
-        if (check) {
+        if (adapt_now) {
+            double ws[2] = {0, 0};
+            for (GroupBlock &b : B) {
+                double part[2];
+                GBLK(g, b, mmc_step_sums_read(b.h, part));
+                ws[0] += part[0]; ws[1] += part[1];
+            }
+            if (mmc_step_balance_rule(ws, &g->balance, &g->adapt_alpha))
+                for (GroupBlock &b : B) GBLK(g, b, mmc_set_step_balance(b.h, (float)g->balance));
+            st.step_balance = g->balance;
+        }
+        if (want_check) {
             double s[MMC_NUM_SUMS] = {0, 0, 0, 0};
             for (GroupBlock &b : B) {
                 double part[MMC_NUM_SUMS];

@@ -40,8 +40,9 @@ enum { MMC_SUM_SLOTS = 64 };   // partial-sum slots per reduced quantity
 //   8, 9   sum |W u0|, sum |grad u0|                                       (h)
 //   10..13 sum max(0, -(K'y)_u), sum |(K'y)_w|, |K'y|^2, primal optimality residual^2   (primal sweep, MODE_DUALOBJ)
 //   14     <f, p> (+ <u0, q1> + <w0, q2>)                                  (k_dual_linear)
-enum { MMC_NUM_SUMS_INT = 16 };
-enum { SUM_RES = 0, SUM_ENERGY = 4, SUM_H = 8, SUM_DUALOBJ = 10, SUM_DUALLIN = 14 };
+//   15, 16 sum ((x+ - x)/tau)^2, sum ((y+ - y)/sigma)^2                     (update sweeps with reduce; step balancing)
+enum { MMC_NUM_SUMS_INT = 18 };
+enum { SUM_RES = 0, SUM_ENERGY = 4, SUM_H = 8, SUM_DUALOBJ = 10, SUM_DUALLIN = 14, SUM_WRES = 15 };
 // MMC_STATIC_MAX_BLOCKS (public header): workgroups of k_h_partials that mmc_h_partials_static has room for
 
 // Division of 0 <= n < 2^31 by a fixed d through one high multiply: n / d = umulhi(n, m) >> s
@@ -84,6 +85,7 @@ struct Geom {
     int chunk;
     FastDiv dv_chunk, dv_per;  // dv_per: chunk * (frames of this launch), set by the launcher
     float alpha, kappa, inv_h;
+    float tau_s, sigma_s;      // step balance: every tau is multiplied by tau_s = s, every sigma by sigma_s = 1/s (1, 1 by default)
     float wsgn;                // sign of w in the temporal rows of K1: -1 (u - w, MultiframeMotionCoupling.m:490-491) or +1 (u + w, :864)
     float radius1, radius2;    // projection radii of the g1 / g2 groups
     // Away from the frame border the column abs-sum of A repeats with period f in both directions.

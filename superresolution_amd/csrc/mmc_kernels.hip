@@ -307,6 +307,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
 
     if (!MMC_PRIMAL_EARLY_X) own_loads(true, false, false, false);      // u, w, cW, cA: only needed from here on
     float part[2] = {0.f, 0.f};
+    float wres[1] = {0.f};        // sum ((x+ - x) / tau)^2: the step-weighted change the step balancing compares
     float dob[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         float *u = FR(a.u, t) + j, *w = FR(a.w, t) + j, *ub = FR(a.ub, t) + j, *wb = FR(a.wb, t) + j;
@@ -326,10 +327,10 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                 const float cgrad = (float)((int)cl + (int)cr + (int)(r + i > 0) + (int)(r + i < g.Ny - 1));
                 const float cw = cWv[i] * g.inv_h;
                 if (MODEL == MODEL_IC) {
-                    tau_u[i] = fast_rcp(cAv[i] + cw + kap * cgrad + fixc);
-                    tau_w[i] = fast_rcp((1.f + kap) * (cw + cgrad) + fixc);
+                    tau_u[i] = g.tau_s * fast_rcp(cAv[i] + cw + kap * cgrad + fixc);
+                    tau_w[i] = g.tau_s * fast_rcp((1.f + kap) * (cw + cgrad) + fixc);
                 } else {
-                    tau_u[i] = fast_rcp(cAv[i] + cw + cgrad);
+                    tau_u[i] = g.tau_s * fast_rcp(cAv[i] + cw + cgrad);
                     tau_w[i] = 0.f;
                 }
             }
@@ -454,7 +455,11 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                 for (int i = 0; i < 4; ++i) {
                     un[i] = fminf(fmaxf(uo[i] - tau_u[i] * KTu[i], 0.f), 1.f);   // G = ind[0,1], :495
                     ubn[i] = 2.f * un[i] - uo[i];
-                    if (REDUCE && i < nv) { part[0] += (un[i] - uo[i]) * (un[i] - uo[i]); part[1] += un[i] * un[i]; }
+                    if (REDUCE && i < nv) {
+                        part[0] += (un[i] - uo[i]) * (un[i] - uo[i]); part[1] += un[i] * un[i];
+                        const float q = (un[i] - uo[i]) / tau_u[i];
+                        wres[0] += q * q;
+                    }
                 }
                 st4m(u, un, nv);
                 st4m(ub, ubn, nv);
@@ -464,7 +469,11 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                     for (int i = 0; i < 4; ++i) {
                         wn[i] = wo[i] - tau_w[i] * KTw[i];
                         wbn[i] = 2.f * wn[i] - wo[i];
-                        if (REDUCE && i < nv) { part[0] += (wn[i] - wo[i]) * (wn[i] - wo[i]); part[1] += wn[i] * wn[i]; }
+                        if (REDUCE && i < nv) {
+                            part[0] += (wn[i] - wo[i]) * (wn[i] - wo[i]); part[1] += wn[i] * wn[i];
+                            const float q = (wn[i] - wo[i]) / tau_w[i];
+                            wres[0] += q * q;
+                        }
                     }
                     st4m(w, wn, nv);
                     st4m(wb, wbn, nv);
@@ -473,7 +482,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
         }
     }
     if (MODE == MODE_DUALOBJ) block_accumulate<4>(dob, a.sums, SUM_DUALOBJ);
-    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES);
+    else if (REDUCE) { block_accumulate<2>(part, a.sums, SUM_RES); __syncthreads(); block_accumulate<1>(wres, a.sums, SUM_WRES); }
 }
 
 // --------------------------------------------------------------------------
@@ -632,6 +641,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
     if (MODE != MODE_STEPS) __syncthreads();
 
     float part[2] = {0.f, 0.f};
+    float wres[1] = {0.f};           // sum ((y+ - y) / sigma)^2: the step-weighted change the step balancing compares
     float diag[2] = {0.f, 0.f};      // MODE_ENERGY: |K x|^2, dual optimality residual^2
     if (active && nb_lds) {
         const float *own = ubl + (4 * rq - g.oy + wpad) + SR * (lc - g.ox);
@@ -693,8 +703,8 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
                     rs2 = fmaxf(hasx ? 2.f : 0.f, hasy ? 2.f : 0.f);
                 }
             }
-            sg1[i] = rs1 > 0.f ? fast_rcp(rs1) : 1.f;
-            sg2[i] = rs2 > 0.f ? fast_rcp(rs2) : 1.f;
+            sg1[i] = g.sigma_s * (rs1 > 0.f ? fast_rcp(rs1) : 1.f);
+            sg2[i] = g.sigma_s * (rs2 > 0.f ? fast_rcp(rs2) : 1.f);
         }
         float *g1t = FR(a.g1t, t) + j, *g1x = FR(a.g1x, t) + j, *g1y = FR(a.g1y, t) + j;
         float *g2t = FR(a.g2t, t) + j, *g2x = FR(a.g2x, t) + j, *g2y = FR(a.g2y, t) + j;
@@ -752,9 +762,11 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
                     n1t[i] *= sc; n1x[i] *= sc; n1y[i] *= sc;
                 }
                 if (REDUCE && i < nv) {
-                    part[0] += (n1t[i] - o1t[i]) * (n1t[i] - o1t[i]) + (n1x[i] - o1x[i]) * (n1x[i] - o1x[i]) +
-                               (n1y[i] - o1y[i]) * (n1y[i] - o1y[i]);
+                    const float dt = n1t[i] - o1t[i], dx = n1x[i] - o1x[i], dy = n1y[i] - o1y[i];
+                    part[0] += dt * dt + dx * dx + dy * dy;
                     part[1] += n1t[i] * n1t[i] + n1x[i] * n1x[i] + n1y[i] * n1y[i];
+                    const float sxy = MODEL == MODEL_ADD ? sg2[i] : sg1[i];
+                    wres[0] += (dt / sg1[i]) * (dt / sg1[i]) + ((dx * dx + dy * dy) / sxy) / sxy;
                 }
             }
             if (pex || !MMC_SKIP_NOPAIR) st4m(g1t, n1t, nv);
@@ -769,9 +781,10 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
                     const float sc = ball_scale(n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i], g.radius2);
                     n2t[i] *= sc; n2x[i] *= sc; n2y[i] *= sc;
                     if (REDUCE && i < nv) {
-                        part[0] += (n2t[i] - o2t[i]) * (n2t[i] - o2t[i]) + (n2x[i] - o2x[i]) * (n2x[i] - o2x[i]) +
-                                   (n2y[i] - o2y[i]) * (n2y[i] - o2y[i]);
+                        const float dt = n2t[i] - o2t[i], dx = n2x[i] - o2x[i], dy = n2y[i] - o2y[i];
+                        part[0] += dt * dt + dx * dx + dy * dy;
                         part[1] += n2t[i] * n2t[i] + n2x[i] * n2x[i] + n2y[i] * n2y[i];
+                        wres[0] += ((dt * dt + dx * dx + dy * dy) / sg2[i]) / sg2[i];
                     }
                 }
                 if (pex || !MMC_SKIP_NOPAIR) st4m(g2t, n2t, nv);
@@ -782,11 +795,13 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
                     ld4(q1o, a.q1 + j); ld4(q2o, a.q2 + j); ld4(x0u, a.u0 + j); ld4(x0w, a.w0 + j);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        q1n[i] = q1o[i] + (uc[i] - x0u[i]);
-                        q2n[i] = q2o[i] + (wc[i] - x0w[i]);
+                        q1n[i] = q1o[i] + g.sigma_s * (uc[i] - x0u[i]);
+                        q2n[i] = q2o[i] + g.sigma_s * (wc[i] - x0w[i]);
                         if (REDUCE && i < nv) {
-                            part[0] += (q1n[i] - q1o[i]) * (q1n[i] - q1o[i]) + (q2n[i] - q2o[i]) * (q2n[i] - q2o[i]);
+                            const float d1 = q1n[i] - q1o[i], d2 = q2n[i] - q2o[i];
+                            part[0] += d1 * d1 + d2 * d2;
                             part[1] += q1n[i] * q1n[i] + q2n[i] * q2n[i];
+                            wres[0] += ((d1 * d1 + d2 * d2) / g.sigma_s) / g.sigma_s;
                         }
                     }
                     st4m(a.q1 + j, q1n, nv); st4m(a.q2 + j, q2n, nv);
@@ -810,7 +825,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
         const size_t o = (size_t)t * g.n + (owner ? R + g.ny * C : 0);
         float po = 0.f, fo = 0.f, sg = 0.f;
         if (owner) {
-            if (MODE == MODE_UPDATE) sg = a.sigp[R + g.ny * C];
+            if (MODE == MODE_UPDATE) sg = g.sigma_s * a.sigp[R + g.ny * C];
             if (MODE == MODE_UPDATE || MODE == MODE_ENERGY) { po = a.p[o]; fo = a.f[o]; }
         }
         const int mq = g.MPq >> 2;
@@ -836,7 +851,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
             } else {
                 const float pn = fminf(fmaxf(po + sg * (s - fo), -1.f), 1.f);
                 a.p[o] = pn;
-                if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; }
+                if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; wres[0] += ((pn - po) / sg) * ((pn - po) / sg); }
             }
         }
     }
@@ -866,10 +881,10 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
             const int i = R + g.ny * C;
             const size_t o = (size_t)t * g.n + i;
             const bool owner = sub == 0;
-            if (MODE == MODE_STEPS) { if (owner) a.p[o] = a.sigp[i]; continue; }
+            if (MODE == MODE_STEPS) { if (owner) a.p[o] = g.sigma_s * a.sigp[i]; continue; }
             float po = 0.f, fo = 0.f, sg = 0.f;
             if (owner) {
-                if (MODE == MODE_UPDATE) sg = a.sigp[i];
+                if (MODE == MODE_UPDATE) sg = g.sigma_s * a.sigp[i];
                 if (MODE == MODE_UPDATE || MODE == MODE_ENERGY) { po = a.p[o]; fo = a.f[o]; }
             }
             const float *win = ubl + (f * R - r0) + SR * (f * C - c0);          // window row of kernel row -wpad
@@ -905,7 +920,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
                 } else {
                     const float pn = fminf(fmaxf(po + sg * (s - fo), -1.f), 1.f);
                     a.p[o] = pn;
-                    if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; }
+                    if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; wres[0] += ((pn - po) / sg) * ((pn - po) / sg); }
                 }
             }
         }
@@ -944,7 +959,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
         if (R >= g.ny || C >= g.nx) continue;
         const int i = R + g.ny * C;
         const size_t o = (size_t)t * g.n + i;
-        const float sg = a.sigp[i];
+        const float sg = g.sigma_s * a.sigp[i];
         if (MODE == MODE_STEPS) { a.p[o] = sg; continue; }
         float acc = 0.f;
 #pragma unroll
@@ -960,11 +975,11 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
             const float po = a.p[o];
             const float pn = fminf(fmaxf(po + sg * (acc - a.f[o]), -1.f), 1.f);
             a.p[o] = pn;
-            if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; }
+            if (REDUCE) { part[0] += (pn - po) * (pn - po); part[1] += pn * pn; wres[0] += ((pn - po) / sg) * ((pn - po) / sg); }
         }
     }
     if (MODE == MODE_ENERGY) { float e[4] = {part[0], epart, diag[0], diag[1]}; block_accumulate<4>(e, a.sums, SUM_ENERGY); }
-    else if (REDUCE) block_accumulate<2>(part, a.sums, SUM_RES + 2);
+    else if (REDUCE) { block_accumulate<2>(part, a.sums, SUM_RES + 2); __syncthreads(); block_accumulate<1>(wres, a.sums, SUM_WRES + 1); }
 }
 
 // --------------------------------------------------------------------------

@@ -256,6 +256,7 @@ extern "C" int mmc_sf_solve(mmc_sf_handle *h, int max_iters, float tol, int chec
     const auto t0 = std::chrono::steady_clock::now();
     mmc_stats st;
     memset(&st, 0, sizeof(st));
+    st.step_balance = 1.0;
     st.primal_energy = st.dual_energy = st.gap = st.dual_infeasibility = std::nan("");      // not evaluated by this solve
     st.opt_res_primal = st.opt_res_dual = st.norm_KTy = st.norm_Kx = std::nan("");
     if (check_every <= 0) check_every = std::max(max_iters, 1);

@@ -109,6 +109,11 @@ class MultiframeMotionCoupling(object):
         self._solver = None
         self._opts = {}
         self.check_every = 100
+        # Not a property of the reference class: how the step sizes are balanced between the primal and the dual side.
+        # 1.0 (default): the preconditioners as they are, tau0 = sigma0 = 1 (:349-351); a number s: every tau times s,
+        # every sigma divided by s; 'adaptive': the library's residual balancing, its stand-in for prost's
+        # 'stepsize','boyd' (:349), whose own rule lives in the absent prost submodule.
+        self.stepBalance = 1.0
         self.flexBoxBackwardAsWritten = True     # framework 'flexBox', 'backward': the terms of :864 as they stand
         self.last_stats = None
 
@@ -238,6 +243,13 @@ class MultiframeMotionCoupling(object):
         if w_plus:
             s.set_flexbox_backward_terms(True)
         s.init()                                                     # masks, h (:431-437), step sizes
+        if isinstance(self.stepBalance, str):
+            if self.stepBalance != "adaptive":
+                s.close()
+                raise ValueError("stepBalance must be a positive number or 'adaptive'")
+            s.set_step_adaptation(True)
+        else:
+            s.step_balance = float(self.stepBalance)
         self._h = s.h
         if self.verbose > 0:
             print("Downsampling operator constructed")

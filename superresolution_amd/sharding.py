@@ -192,7 +192,11 @@ def sharded_h(engine, device=None):
     return float(s[0] / s[1])
 
 
-def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=None, callback=None, diagnostics=None):
+ADAPT_EVERY = 50      # iterations between two looks at the step balance (mmc_solve's cadence)
+
+
+def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=None, callback=None, diagnostics=None,
+                  adapt_steps=False):
     """The loop of mmc_solve for a block with neighbours.
 
     `engine` provides L, sweep_primal(t0,t1,reduce), sweep_dual(t0,t1,reduce),
@@ -201,6 +205,9 @@ def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=N
     diagnostics: evaluate energies, gap and optimality residuals at every check and stop on the
     residual test (see mmc_stats in include/mmc_hip.h); None = when there is a tolerance or a
     callback, as mmc_solve does.  Needs engine.diag_partials() and engine.problem_size().
+    adapt_steps: choose the step balance by residual balancing as mmc_solve does with
+    mmc_set_step_adaptation (the step-weighted change sums added up over the ranks, the library's
+    rule applied on every rank).  Needs a FrameBlockSolver.
     """
     L = engine.L
     if getattr(exchanger, "on_device", False) and hasattr(engine, "params"):
@@ -213,8 +220,14 @@ def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=N
     if diagnostics is None:
         diagnostics = (tol > 0 or callback is not None) and hasattr(engine, "diag_partials")
     reqs_dual = None
+    balance, alpha = None, None
+    if adapt_steps:
+        import ctypes as C
+        balance, alpha = C.c_double(engine.step_balance), C.c_double(0.5)
     for it in range(max_iters):
-        check = ((it + 1) % check_every == 0) or it == max_iters - 1
+        want_check = ((it + 1) % check_every == 0) or it == max_iters - 1
+        adapt_now = adapt_steps and (it + 1) % ADAPT_EVERY == 0
+        check = want_check or adapt_now            # sweeps with reduced sums
         if check:
             engine.sums_reset()
         # primal sweep: the first frame needs the previous block's temporal duals
@@ -236,7 +249,13 @@ def solve_sharded(engine, exchanger, max_iters, tol=0.0, check_every=0, device=N
             exchanger.wait(reqs_x)
         reqs_dual = exchanger.start_dual()
         stats["iterations"] = it + 1
-        if check:
+        if adapt_now:
+            ws = allreduce_sums(engine.step_sums_read(), device)
+            arr = (C.c_double * 2)(float(ws[0]), float(ws[1]))
+            if engine._lib.mmc_step_balance_rule(arr, C.byref(balance), C.byref(alpha)):
+                engine.step_balance = balance.value
+            stats["step_balance"] = balance.value
+        if want_check:
             s = allreduce_sums(engine.sums_read(), device)
             tiny = 1e-30
             stats["res_primal"] = float(np.sqrt(s[0]) / max(np.sqrt(s[1]), tiny))

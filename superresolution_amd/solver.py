@@ -219,6 +219,28 @@ class FrameBlockSolver(object):
     def sync(self):
         self._check(self._lib.mmc_sync(self._h))
 
+    # -- step balance ---------------------------------------------------------
+    @property
+    def step_balance(self):
+        """Global factor s: every tau times s, every sigma divided by s (1 by default)."""
+        v = C.c_float()
+        self._check(self._lib.mmc_get_step_balance(self._h, C.byref(v)))
+        return float(v.value)
+
+    @step_balance.setter
+    def step_balance(self, s):
+        self._check(self._lib.mmc_set_step_balance(self._h, float(s)))
+
+    def set_step_adaptation(self, enable=True):
+        """mmc_solve chooses the step balance by residual balancing every 50 iterations."""
+        self._check(self._lib.mmc_set_step_adaptation(self._h, int(bool(enable))))
+
+    def step_sums_read(self):
+        """This block's sums of ((x+ - x)/tau)^2 and ((y+ - y)/sigma)^2 of the last sweeps with reduce (synchronises)."""
+        out = (C.c_double * 2)()
+        self._check(self._lib.mmc_step_sums_read(self._h, out))
+        return np.array(list(out), dtype=np.float64)
+
     # -- diagnostics: energies, gap, optimality residuals ----------------------
     def set_diagnostics(self, mode):
         """_capi.DIAG_OFF / DIAG_AUTO (default: when the solve has a tolerance or a callback) / DIAG_ALWAYS."""
@@ -486,6 +508,14 @@ class SequenceGroupSolver(object):
 
     def set_diagnostics(self, mode):
         self._check(self._lib.mmc_group_set_diagnostics(self._g, int(mode)))
+
+    def set_step_balance(self, s):
+        """One global factor for every block: every tau times s, every sigma divided by s."""
+        self._check(self._lib.mmc_group_set_step_balance(self._g, float(s)))
+
+    def set_step_adaptation(self, enable=True):
+        """mmc_group_solve chooses the step balance by residual balancing every 50 iterations."""
+        self._check(self._lib.mmc_group_set_step_adaptation(self._g, int(bool(enable))))
 
     def init(self):
         self._check(self._lib.mmc_group_init(self._g))
