@@ -75,6 +75,13 @@ def test_ranks_on_their_own_gpus_over_rccl(tmp_path, world, nc, kappa, direction
     _run_and_check(tmp_path, world, nc, kappa, direction, "nccl")
 
 
+def test_one_rank_over_rccl(tmp_path):
+    """The RCCL set-up of the sharded driver on the one GPU every box has: communicator bound to the device
+    at init, sums all-reduced on the device, the library's stream as torch's current stream.  (The
+    device-to-device frames need a second GPU: the test above.)"""
+    _run_and_check(tmp_path, 1, 4, 0.25, "backward", "nccl")
+
+
 def _run_and_check(tmp_path, world, nc, kappa, direction, backend):
     iters = 30
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
