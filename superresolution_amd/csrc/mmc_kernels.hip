@@ -93,6 +93,9 @@ __device__ __forceinline__ void st4m(float *p, const float (&s)[4], int nv) {
 #ifndef MMC_SCATTER_SCU
 #define MMC_SCATTER_SCU 5       // source pixels per thread and pass of the primal sweep's scatter
 #endif
+#ifndef MMC_ATP_QUAD
+#define MMC_ATP_QUAD 1          // zoom 4, kernels beyond 3 x 3 low-res taps: A'p of a row quad with 16-byte weight reads
+#endif
 #ifndef MMC_OCC_DUAL
 #define MMC_OCC_DUAL 1
 #endif
@@ -386,6 +389,37 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                         for (int jr = 0; jr < 3; ++jr)
                             s += wk[br + 4 * jr + 48 * jc] * pv[dR - jr + 2][jc];
                     ATp[i] = s;
+                }
+            } else if (F == 4 && MMC_ATP_QUAD && !qborder) {
+                // Interior quads at zoom 4, any kernel size.  Quad row i has kernel row phase (ph + i) & 3 and
+                // low-res row R0 + ((ph + i) >> 2), ph the same in the whole tile: the four phases of the kernel
+                // rows 4 jr .. 4 jr + 3 are one 16-byte read of the table, and a column of the low-res window is
+                // walked once for the four rows.  Sums are kept by phase; each adds its taps in the order of
+                // the generic path below.
+                const int x0 = r - g.oy, R0 = x0 >> 2, ph = x0 & 3;
+                float tq[4] = {0.f, 0.f, 0.f, 0.f};
+                const float *ckc = ckp + g.MP * bc;
+                const float *plc = pl + (R0 + 1 - Rbase) + g.PR * (Chi - Cbase);
+#pragma unroll 1
+                for (int jc = 0; jc < g.Jc; ++jc) {
+                    const float4 *wq = reinterpret_cast<const float4 *>(ckc + 4 * g.MP * jc);
+                    const float *pp = plc - g.PR * jc;
+                    float pa = pp[0];                           // low-res row R0 + 1 - jr: rows whose phase wrapped
+#pragma unroll 1
+                    for (int jr = 0; jr < g.Jr; ++jr) {
+                        const float pb = pp[-jr - 1];           // low-res row R0 - jr
+                        const float4 wv = wq[jr];
+                        tq[0] += wv.x * (ph > 0 ? pa : pb);
+                        tq[1] += wv.y * (ph > 1 ? pa : pb);
+                        tq[2] += wv.z * (ph > 2 ? pa : pb);
+                        tq[3] += wv.w * pb;
+                        pa = pb;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = (ph + i) & 3;
+                    ATp[i] = k == 0 ? tq[0] : k == 1 ? tq[1] : k == 2 ? tq[2] : tq[3];
                 }
             } else {
                 // Generic path.  The replicate border of the blur (helpers/RepConvMtx.m:23-32) folds
