@@ -878,6 +878,7 @@ static int build_data_operator(mmc_handle *h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
 
     free_correction(h);
+    g.uc_margin = 0;
     if (!e_row.empty()) {
         // transpose: rows = high-res pixels
         std::vector<int> hr_ids(e_col);
@@ -903,6 +904,12 @@ static int build_data_operator(mmc_handle *h) {
             return rc;
         a.ne = (int)e_row.size();
         a.net = (int)hr_ids.size();
+        int margin = 0;
+        for (int hr : hr_ids) {
+            const int c = hr / g.Ny, r = hr - c * g.Ny;
+            margin = std::max(margin, std::min(std::min(r, g.Ny - 1 - r), std::min(c, g.Nx - 1 - c)) + 1);
+        }
+        g.uc_margin = (margin + 3) & ~3;
         void *pc = nullptr, *uc = nullptr;
         HIPCHK(h, hipMalloc(&pc, (size_t)h->L * g.n * sizeof(float)));
         h->eallocs.push_back(pc);

@@ -92,6 +92,8 @@ struct Geom {
     // cA_margin > 0: pixels at least that far from every border take it from cA_tab (f = 4 only)
     // instead of reading the cA plane.
     int cA_margin;
+    // E'p (ucorr) is zero at pixels at least this far from every border (0: nowhere known to be zero)
+    int uc_margin;
     float cA_tab[16];          // [row mod 4 + 4 * (column mod 4)]
     int fixed;                 // 1: first frame of the sequence is pinned to (u0, w0), MultiframeMotionCoupling.m:535-572
     int dbg;                   // ablation switches for kernel tuning (env MMC_DEBUG); read only in -DMMC_ABLATION builds

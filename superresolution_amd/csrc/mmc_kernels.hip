@@ -459,7 +459,8 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                 }
             }
             float KTu[4], KTw[4];
-            if (a.ucorr) {      // rows of A that deviate from the composite kernel
+            // rows of A that deviate from the composite kernel: near the frame border only
+            if (a.ucorr && (r < g.uc_margin || r + 4 > g.Ny - g.uc_margin || c < g.uc_margin || c >= g.Nx - g.uc_margin)) {
                 float uc[4];
                 ld4(uc, a.ucorr + (size_t)t * g.N + j);
 #pragma unroll
