@@ -313,7 +313,7 @@ int mmc_stats_from_diag(const double diag[MMC_NUM_DIAG], double n_primal, double
  * of every fixed-iteration comparison with the oracle.  mmc_set_step_adaptation(h, 1) lets mmc_solve
  * choose s itself by residual balancing: every 50 iterations it compares the step-weighted changes
  * P = ||(x+ - x) / tau|| and D = ||(y+ - y) / sigma|| and, with Delta = 1.5, alpha = 0.5 at first
- * and alpha <- 0.95 alpha after every change, sets s <- s / (1 - alpha) when P > Delta D and
+ * and alpha <- 0.8 alpha after every change, sets s <- s / (1 - alpha) when P > Delta D and
  * s <- s (1 - alpha) when P < D / Delta (mmc_step_balance_rule; the rule of adaptive PDHG, of which
  * prost's 'boyd' setting is an instance whose constants live in the absent prost submodule: own
  * definition, not a reproduction).  A block driven sweep by sweep reads its share of P^2 and D^2 with

@@ -598,7 +598,7 @@ def prox_Fstar(P, y, S):
     return out
 
 
-STEP_ADAPT_EVERY, STEP_DELTA, STEP_ETA = 50, 1.5, 0.95
+STEP_ADAPT_EVERY, STEP_DELTA, STEP_ETA = 50, 1.5, 0.8
 
 
 def step_balance_rule(P2, D2, balance, alpha):

@@ -1184,7 +1184,7 @@ extern "C" int mmc_set_step_adaptation(mmc_handle *h, int enable) {
 
 extern "C" int mmc_step_balance_rule(const double sums[2], double *balance, double *alpha) {
     if (!sums || !balance || !alpha) return 0;
-    const double Delta = 1.5, eta = 0.95;
+    const double Delta = 1.5, eta = 0.8;
     const double P = std::sqrt(std::max(sums[0], 0.0)), D = std::sqrt(std::max(sums[1], 0.0));
     if (!(P > 0.0) || !(D > 0.0) || !std::isfinite(P) || !std::isfinite(D)) return 0;
     double s = *balance;
