@@ -427,6 +427,11 @@ int mmc_debug_steps_update(mmc_handle *h, float *tau_u, float *tau_w);
  * Results do not depend on it. */
 size_t mmc_debug_plane_skew(const mmc_handle *h);
 
+/* 1 after mmc_init when the sweeps apply the composite kernel of sampler and blur as two 1-D passes: zoom 4, the
+ * kernel an outer product (the samplers of helpers/samplingOperator.m:146 are, a Gaussian blur is) and larger
+ * than 3 x 3 low-res taps.  Results agree with the one-pass form to float32 rounding. */
+int mmc_debug_separable(const mmc_handle *h);
+
 /* ---- Classical single-frame super-resolution (the reference's comparison methods) ------------
  * classical methods/singleframeMotionSR_mitzel_prost.m, ..._mitzel_prost_fast.m and
  * ..._unger_prost.m assemble, after their flow estimation (which stays on the reference path),

@@ -146,6 +146,7 @@ SIGNATURES = {
     "mmc_debug_steps": (C.c_int, [_H, _fp, _fp, _fp, _fp, _fp]),
     "mmc_debug_steps_update": (C.c_int, [_H, _fp, _fp]),
     "mmc_debug_plane_skew": (C.c_size_t, [_H]),
+    "mmc_debug_separable": (C.c_int, [_H]),
     "mmc_sf_create": (C.c_int, [C.POINTER(mmc_sf_params), C.POINTER(_H)]),
     "mmc_sf_destroy": (C.c_int, [_H]),
     "mmc_sf_last_error": (C.c_char_p, [_H]),

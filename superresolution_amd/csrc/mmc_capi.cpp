@@ -277,6 +277,7 @@ static int choose_plane_skew(mmc_handle *h, const std::vector<float *> &raw, siz
 }
 
 extern "C" size_t mmc_debug_plane_skew(const mmc_handle *h) { return h ? h->plane_skew : 0; }
+extern "C" int mmc_debug_separable(const mmc_handle *h) { return h ? h->g.sep : 0; }
 
 // geometry_only: the handle carries the geometry and the data operator D*B (composite kernel, its row
 // and column sums) and none of the per-pixel state; the single-frame solve owns such a handle.
@@ -385,6 +386,7 @@ static int create_handle(const mmc_params *p, bool geometry_only, mmc_handle **o
         if ((rc = dev_alloc(h, &a.sigp, (size_t)g.n)) != MMC_OK) return bail(rc);
         if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
         if ((rc = dev_alloc(h, &a.ckq, (size_t)(MMC_MAX_CK + 8) * MMC_MAX_CK)) != MMC_OK) return bail(rc);
+        if ((rc = dev_alloc(h, &a.ksep, (size_t)3 * MMC_KSEP_PITCH)) != MMC_OK) return bail(rc);
         if ((rc = dev_alloc(h, &a.ckp, (size_t)(MMC_MAX_CK + p->factor) * (MMC_MAX_CK + p->factor))) != MMC_OK) return bail(rc);
         if ((rc = dev_alloc(h, &a.sums, (size_t)MMC_NUM_SUMS_INT * MMC_SUM_SLOTS)) != MMC_OK) return bail(rc);
         if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return bail(MMC_ERR_HIP); }
@@ -420,6 +422,7 @@ static int create_handle(const mmc_params *p, bool geometry_only, mmc_handle **o
     if ((rc = dev_alloc(h, &a.sigp, (size_t)g.n)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.cker, (size_t)MMC_MAX_CK * MMC_MAX_CK)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.ckq, (size_t)(MMC_MAX_CK + 8) * MMC_MAX_CK)) != MMC_OK) return bail(rc);
+    if ((rc = dev_alloc(h, &a.ksep, (size_t)3 * MMC_KSEP_PITCH)) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.ckp, (size_t)(MMC_MAX_CK + p->factor) * (MMC_MAX_CK + p->factor))) != MMC_OK) return bail(rc);
     if ((rc = dev_alloc(h, &a.bbox, (size_t)(h->L + 1) * g.ntiles * 4)) != MMC_OK) return bail(rc);
     { float **fx[] = {&a.q1, &a.q2, &a.u0, &a.w0}; for (float **pp : fx) if ((rc = dev_alloc(h, pp, (size_t)g.N)) != MMC_OK) return bail(rc); }
@@ -777,6 +780,33 @@ static int build_data_operator(mmc_handle *h) {
     for (int nn = 0; nn < g.CW; ++nn)
         for (int mm = 0; mm < g.CH; ++mm) ckq[(size_t)(g.wpad + mm) + (size_t)g.MPq * nn] = ckf[(size_t)mm + (size_t)g.CH * nn];
     HIPCHK(h, hipMemcpyAsync(h->a.ckq, ckq.data(), ckq.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    // Separable composite kernel (the samplers are products of two 1-D factors, samplingOperator.m:146; a
+    // Gaussian blur is one as well): ck = ky kx' up to float32 rounding.  Worth two passes only beyond 3 x 3
+    // low-res taps.
+    g.sep = 0;
+    std::vector<float> ksep((size_t)3 * MMC_KSEP_PITCH, 0.f);
+    if (MMC_SEPARABLE && f == 4 && g.Jr * g.Jc > 9 && g.SRp <= 128 && g.MP <= MMC_KSEP_PITCH && g.NP <= MMC_KSEP_PITCH && g.MPq <= MMC_KSEP_PITCH) {
+        size_t piv = 0;
+        for (size_t i = 1; i < ck.size(); ++i) if (std::fabs(ck[i]) > std::fabs(ck[piv])) piv = i;
+        const int pm = (int)(piv % (size_t)g.CH), pn = (int)(piv / (size_t)g.CH);
+        if (ck[piv] != 0.0) {
+            double err = 0.0;
+            for (int nn = 0; nn < g.CW; ++nn)
+                for (int mm = 0; mm < g.CH; ++mm)
+                    err = std::max(err, std::fabs(ck[(size_t)mm + (size_t)g.CH * nn] -
+                                                  ck[(size_t)mm + (size_t)g.CH * pn] * ck[(size_t)pm + (size_t)g.CH * nn] / ck[piv]));
+            if (err <= 1e-8 * std::fabs(ck[piv])) {
+                g.sep = 1;
+                for (int mm = 0; mm < g.CH; ++mm) {
+                    const float v = (float)ck[(size_t)mm + (size_t)g.CH * pn];
+                    ksep[(size_t)mm] = v;
+                    ksep[(size_t)2 * MMC_KSEP_PITCH + g.wpad + mm] = v;
+                }
+                for (int nn = 0; nn < g.CW; ++nn) ksep[(size_t)MMC_KSEP_PITCH + nn] = (float)(ck[(size_t)pm + (size_t)g.CH * nn] / ck[piv]);
+            }
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->a.ksep, ksep.data(), ksep.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
 
     auto clampi = [](int v, int hi) { return std::min(std::max(v, 0), hi); };

@@ -58,6 +58,10 @@ static inline FastDiv make_fastdiv(unsigned d) {
     return r;
 }
 
+#ifndef MMC_SEPARABLE
+#define MMC_SEPARABLE 1     // 0: never split a separable composite kernel into its two factors
+#endif
+#define MMC_KSEP_PITCH (MMC_MAX_CK + 8)       // floats between the three vectors of Arrays::ksep
 // identity bits (Arrays::idq): one byte per row quad, ceil(Ny / 4) quads per column, column after column
 #define MMC_IDQ_PER_FRAME(g) ((size_t)(((g).Ny + 3) >> 2) * (size_t)(g).Nx)
 
@@ -94,6 +98,9 @@ struct Geom {
     int cA_margin;
     // E'p (ucorr) is zero at pixels at least this far from every border (0: nowhere known to be zero)
     int uc_margin;
+    // 1: zoom 4, the composite kernel is an outer product and reaches beyond 3 x 3 low-res taps: the sweeps apply
+    // its two factors one after the other (a.ksep)
+    int sep;
     float cA_tab[16];          // [row mod 4 + 4 * (column mod 4)]
     int fixed;                 // 1: first frame of the sequence is pinned to (u0, w0), MultiframeMotionCoupling.m:535-572
     int dbg;                   // ablation switches for kernel tuning (env MMC_DEBUG); read only in -DMMC_ABLATION builds
@@ -118,6 +125,8 @@ struct Arrays {
     float *cker;               // composite kernel, CH x CW column-major
     float *ckp;                // the same, zero-padded to MP x NP
     float *ckq;                // the same, wpad zero rows on top, zero-padded to MPq x CW
+    // Geom::sep: the composite kernel is the outer product ky kx' (separable blur and sampler):
+    float *ksep;               // ky zero-padded to MP | kx zero-padded to NP | ky with wpad zero rows on top, padded to MPq; MMC_KSEP_PITCH apart
     // Sparse correction E = A - (composite kernel with one replicate clamp), non-zero only on the low-res
     // pixels whose sampling rows are not the interior ones; all null when the sampler has none.
     int ne, net;               // rows of E (low-res pixels) and of E' (high-res pixels)

@@ -99,7 +99,7 @@ __device__ __forceinline__ void st4m(float *p, const float (&s)[4], int nv) {
 #ifndef MMC_OCC_DUAL
 #define MMC_OCC_DUAL 1
 #endif
-template <int MODEL, int MODE, bool REDUCE, int F>
+template <int MODEL, int MODE, bool REDUCE, int F, bool SEPK = false>
 __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     // In the update sweep the tap weights are scattered along with the duals, which yields the
@@ -110,6 +110,11 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
     fx64 *acc3 = acc2 + TILE_R * TILE_C;
     float *ckp = lds + 6 * TILE_R * TILE_C;
     float *pl = ckp + ((g.MP * g.NP + 3) & ~3);
+    // Separable composite kernel (Geom::sep): column sums of the low-res window per tile column, and the two factors
+    constexpr bool SEP = SEPK && F == 4 && MODE != MODE_STEPS && MODE != MODE_STEPS_UPD;    // the launcher picks SEPK from Geom::sep
+    float *tl = pl + ((g.PR * g.PC + 3) & ~3);          // PR x TILE_C
+    float *kys = tl + ((g.PR * TILE_C + 3) & ~3);       // ky, MP floats (16-byte aligned)
+    float *kxs = kys + g.MP;                            // kx, NP floats
     const int f = F > 0 ? F : g.f;
     const int tid = threadIdx.x;
     int tile, trel;
@@ -213,6 +218,10 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
     }
     if (MODE != MODE_STEPS) {
         for (int k = tid; k < g.MP * g.NP; k += MMC_THREADS) ckp[k] = a.ckp[k];
+        if (SEP) {
+            if (tid < g.MP) kys[tid] = a.ksep[tid];
+            if (tid >= 64 && tid - 64 < g.NP) kxs[tid - 64] = a.ksep[MMC_KSEP_PITCH + tid - 64];
+        }
         for (int k = tid; k < g.PR * g.PC; k += MMC_THREADS) {
             const int pc = fdiv(k, g.dv_PR), pr = k - pc * g.PR;
             const int R = Rbase + pr, C = Cbase + pc;
@@ -308,6 +317,31 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
         __syncthreads();
     }
 
+    // Separable kernel, first factor: for every low-res row of the window and every column of the tile the sum
+    // over the low-res columns, tl[row + PR * column] = sum_jc kx[phase + 4 jc] p[row, Chi - jc]; the first and
+    // the last column of the frame add the virtual columns that the replicate border of the blur folds onto
+    // them (helpers/RepConvMtx.m:23-32).  Done here, after the scatter, where few registers are live.
+    if (SEP) {
+        const int cvlast = max(4 * (g.nx - 1) + g.ox + g.CW - 1, g.Nx - 1);
+#pragma unroll 1
+        for (int k = tid; k < g.PR * TILE_C; k += MMC_THREADS) {
+            const int cl = fdiv(k, g.dv_PR), pr = k - cl * g.PR;
+            const int cc = c0 + cl;
+            const int cvA = cc == 0 ? min(g.ox, 0) : cc, cvB = cc == g.Nx - 1 ? cvlast : (cc < g.Nx ? cc : cc - 1);
+            float sacc = 0.f;
+#pragma unroll 1
+            for (int cv = cvA; cv <= cvB; ++cv) {
+                const int xcv = cv - g.ox;
+                const float *pp = pl + pr + g.PR * ((xcv >> 2) - Cbase);
+                const float *kw = kxs + (xcv & 3);
+#pragma unroll 1
+                for (int jc = 0; jc < g.Jc; ++jc) sacc += kw[4 * jc] * pp[-g.PR * jc];
+            }
+            tl[k] = sacc;
+        }
+        __syncthreads();
+    }
+
     if (!MMC_PRIMAL_EARLY_X) own_loads(true, false, false, false);      // u, w, cW, cA: only needed from here on
     float part[2] = {0.f, 0.f};
     float wres[1] = {0.f};        // sum ((x+ - x) / tau)^2: the step-weighted change the step balancing compares
@@ -389,6 +423,49 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                         for (int jr = 0; jr < 3; ++jr)
                             s += wk[br + 4 * jr + 48 * jc] * pv[dR - jr + 2][jc];
                     ATp[i] = s;
+                }
+            } else if (SEP && (r == 0 || r + 4 >= g.Ny)) {
+                // second factor for the quads with the first or the last row of the frame: that row adds the
+                // virtual rows folded onto it
+                const int rvlast = max(4 * (g.ny - 1) + g.oy + g.CH - 1, g.Ny - 1);
+                const float *tcl = tl + g.PR * lc - Rbase;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ri = r + i;
+                    const int rv0 = ri == 0 ? min(g.oy, 0) : ri, rv1 = ri == g.Ny - 1 ? rvlast : ri;
+                    float sacc = 0.f;
+#pragma unroll 1
+                    for (int rv = rv0; rv <= rv1; ++rv) {
+                        const int x = rv - g.oy;
+                        const float *tc = tcl + (x >> 2);
+                        const float *kw = kys + (x & 3);
+#pragma unroll 1
+                        for (int jr = 0; jr < g.Jr; ++jr) sacc += kw[4 * jr] * tc[-jr];
+                    }
+                    ATp[i] = sacc;
+                }
+            } else if (SEP) {
+                // second factor of the separable kernel on the column sums: phases and low-res rows of the quad as
+                // in the next branch
+                const int x0 = r - g.oy, R0 = x0 >> 2, ph = x0 & 3;
+                float tq[4] = {0.f, 0.f, 0.f, 0.f};
+                const float4 *wq = reinterpret_cast<const float4 *>(kys);
+                const float *tcol = tl + (R0 + 1 - Rbase) + g.PR * lc;
+                float pa = tcol[0];
+#pragma unroll 1
+                for (int jr = 0; jr < g.Jr; ++jr) {
+                    const float pb = tcol[-jr - 1];
+                    const float4 wv = wq[jr];
+                    tq[0] += wv.x * (ph > 0 ? pa : pb);
+                    tq[1] += wv.y * (ph > 1 ? pa : pb);
+                    tq[2] += wv.z * (ph > 2 ? pa : pb);
+                    tq[3] += wv.w * pb;
+                    pa = pb;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = (ph + i) & 3;
+                    ATp[i] = k == 0 ? tq[0] : k == 1 ? tq[1] : k == 2 ? tq[2] : tq[3];
                 }
             } else if (F == 4 && MMC_ATP_QUAD && !qborder) {
                 // Interior quads at zoom 4, any kernel size.  Quad row i has kernel row phase (ph + i) & 3 and
@@ -533,7 +610,15 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
 // low-res duals p it owns from it: those whose first high-res pixel (f R, f C)
 // lies in the tile.  Groups of adjacent lanes share a low-res pixel and split
 // the composite-kernel columns among them.
-template <int MODEL, int MODE, bool REDUCE, int F>
+// Floats of the dual sweep's LDS between the data-term window and the tap regions: per-wave partial sums and the
+// kernel table, or (separable kernel at zoom 4) the row sums of the window and the two factors.
+__host__ __device__ inline int dual_mid_floats(const Geom &g, bool sep) {
+    const int f = g.f;
+    if (!sep) return (((MMC_THREADS / 64) * (TILE_R / f) * (TILE_C / f) + 3) & ~3) + g.MPq * g.CW;
+    return (((TILE_R / 4) * (TILE_C + g.CW - 4) + 3) & ~3) + g.MPq + ((g.CW + 3) & ~3);
+}
+
+template <int MODEL, int MODE, bool REDUCE, int F, bool SEPK = false>
 __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
     const int f = F > 0 ? F : g.f;
@@ -561,7 +646,13 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
     float *ubl = lds;                                   // SR x SC window of xbar_u
     float *psum = lds + ((SR * SC + 3) & ~3);           // [NWV waves][nlr] partial sums of A xbar_u
     float *ckq = psum + ((NWV * nlr + 3) & ~3);         // composite kernel shifted down by wpad rows, MPq x CW
-    float *wu = ckq + g.MPq * g.CW;                     // tap region of the warped frame, xbar_u
+    // Separable composite kernel (Geom::sep): the row sums of the window and the two factors take the place of
+    // the partial sums and the kernel table
+    const bool SEP = SEPK && F == 4 && VEC;             // the launcher picks SEPK from Geom::sep
+    float *sl = psum;                                   // LRR x SC: sum_m ky[m] window[4 R + m, column]
+    float *kys = sl + ((LRR * SC + 3) & ~3);            // ky shifted down by wpad rows, MPq floats
+    float *kxs = kys + g.MPq;                           // kx, CW floats
+    float *wu = SEPK ? psum + dual_mid_floats(g, true) : ckq + g.MPq * g.CW;      // tap region of the warped frame, xbar_u
     float *ww = wu + MMC_WARP_MAX;                      // ... and xbar_w
     const float *ub = FR(a.ub, t), *wb = FR(a.wb, t);
     const float *ubW = FR(a.ub, isIF ? t + 1 : t), *wbW = FR(a.wb, isIF ? t + 1 : t);   // warped frame
@@ -626,7 +717,10 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
     // stage the xbar_u window, replicate border (helpers/RepConvMtx.m:23-32)
     if (MODE != MODE_STEPS && !ABL(512)) {
         const int wr0 = r0 + g.oy - wpad, wc0 = c0 + g.ox;
-        if (VEC) {
+        if (VEC && SEP) {
+            if (tid < g.MPq) kys[tid] = a.ksep[2 * MMC_KSEP_PITCH + tid];
+            if (tid >= 64 && tid - 64 < g.CW) kxs[tid - 64] = a.ksep[MMC_KSEP_PITCH + tid - 64];
+        } else if (VEC) {
             for (int k = tid; k < g.MPq * g.CW; k += MMC_THREADS) ckq[k] = a.ckq[k];
         }
         if (VEC && wr0 >= 0 && wr0 + SR <= g.Ny && wc0 >= 0 && wc0 + SC <= g.Nx) {
@@ -865,12 +959,33 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
         }
         const int mq = g.MPq >> 2;
         float s = 0.f;
-        for (int nn = part4; nn < g.CW; nn += 4) {
-            const float4 *col = reinterpret_cast<const float4 *>(ubl + f * Rl + SR * (f * Cl + nn));
-            const float4 *ck = reinterpret_cast<const float4 *>(ckq + g.MPq * nn);
-            for (int m4 = 0; m4 < mq; ++m4) {
-                const float4 cv = ck[m4], dv = col[m4];
-                s += cv.x * dv.x + cv.y * dv.y + cv.z * dv.z + cv.w * dv.w;
+        if (SEP) {
+            // first factor down the rows of every window column, for the 16 low-res rows of the tile; then each
+            // lane takes every fourth column of the second factor
+            const float4 *kw = reinterpret_cast<const float4 *>(kys);
+#pragma unroll 1
+            for (int k = tid; k < LRR * SC; k += MMC_THREADS) {
+                const float4 *col = reinterpret_cast<const float4 *>(ubl + f * (k % LRR) + SR * (k / LRR));
+                float sr = 0.f;
+#pragma unroll 1
+                for (int m4 = 0; m4 < mq; ++m4) {
+                    const float4 cv = kw[m4], dv = col[m4];
+                    sr += cv.x * dv.x + cv.y * dv.y + cv.z * dv.z + cv.w * dv.w;
+                }
+                sl[k] = sr;
+            }
+            __syncthreads();
+            const float *srow = sl + Rl + LRR * (f * Cl);
+#pragma unroll 1
+            for (int nn = part4; nn < g.CW; nn += 4) s += kxs[nn] * srow[LRR * nn];
+        } else {
+            for (int nn = part4; nn < g.CW; nn += 4) {
+                const float4 *col = reinterpret_cast<const float4 *>(ubl + f * Rl + SR * (f * Cl + nn));
+                const float4 *ck = reinterpret_cast<const float4 *>(ckq + g.MPq * nn);
+                for (int m4 = 0; m4 < mq; ++m4) {
+                    const float4 cv = ck[m4], dv = col[m4];
+                    s += cv.x * dv.x + cv.y * dv.y + cv.z * dv.z + cv.w * dv.w;
+                }
             }
         }
         s += __shfl_xor(s, 1, 64);
@@ -1021,14 +1136,20 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
 // sparse border correction of the data operator (samplers whose rows near the
 // frame border deviate from the interior taps): pcorr = E xbar_u, ucorr = E' p
 // --------------------------------------------------------------------------
+// A row of E has up to a few hundred entries (the patch of a low-res pixel): 16 adjacent lanes share a row,
+// take its entries 16 apart (their index and value loads coalesce) and add their partial sums by lane exchanges.
+constexpr int CORR_P_LANES = 16;
 __global__ __launch_bounds__(MMC_THREADS) void k_corr_p(Geom g, Arrays a, int t0, int nf) {
-    const int idx = blockIdx.x * MMC_THREADS + threadIdx.x;
-    if (idx >= a.ne * nf) return;
-    const int tr = idx / a.ne, e = idx - tr * a.ne, t = t0 + tr;
+    const int idx = (blockIdx.x * MMC_THREADS + threadIdx.x) / CORR_P_LANES, sub = threadIdx.x & (CORR_P_LANES - 1);
+    const bool live = idx < a.ne * nf;          // whole groups of 16 lanes are live or not; all lanes reach the exchanges
+    const int tr = live ? idx / a.ne : 0, e = live ? idx - tr * a.ne : 0, t = t0 + tr;
     const float *ub = FR(a.ub, t);
     float s = 0.f;
-    for (int k = a.e_ptr[e]; k < a.e_ptr[e + 1]; ++k) s += a.e_val[k] * ub[a.e_col[k]];
-    a.pcorr[(size_t)t * g.n + a.e_row[e]] = s;
+    if (live)
+        for (int k = a.e_ptr[e] + sub; k < a.e_ptr[e + 1]; k += CORR_P_LANES) s += a.e_val[k] * ub[a.e_col[k]];
+#pragma unroll
+    for (int off = 1; off < CORR_P_LANES; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (live && sub == 0) a.pcorr[(size_t)t * g.n + a.e_row[e]] = s;
 }
 
 __global__ __launch_bounds__(MMC_THREADS) void k_corr_u(Geom g, Arrays a, int t0, int nf) {
@@ -1397,24 +1518,32 @@ static Geom with_launch_frames(const Geom &g0, int nf) {
     return g;
 }
 
-template <int MODEL, int F>
+template <int MODEL, int F, bool SEPK>
 static void launch_primal4_m(const Geom &g0, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     const Geom g = with_launch_frames(g0, nf);
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
-    const size_t lds = (size_t)(6 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + g.PR * g.PC) * sizeof(float) + lds_pad();
-    if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
-    else if (mode == MODE_DUALOBJ) hipLaunchKernelGGL((k_primal4<MODEL, MODE_DUALOBJ, false, F>), grid, block, lds, s, g, a, t0, nf);
-    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
-    else if (mode == MODE_STEPS_UPD) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS_UPD, false, F>), grid, block, lds, s, g, a, t0, nf);
-    else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0, nf);
-    else hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0, nf);
+    const size_t lds = (size_t)(6 * TILE_R * TILE_C + ((g.MP * g.NP + 3) & ~3) + ((g.PR * g.PC + 3) & ~3) +
+                                (g.sep ? ((g.PR * TILE_C + 3) & ~3) + g.MP + g.NP : 0)) * sizeof(float) + lds_pad();
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_primal4<MODEL, MODE_RAW, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_DUALOBJ) hipLaunchKernelGGL((k_primal4<MODEL, MODE_DUALOBJ, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_STEPS_UPD) hipLaunchKernelGGL((k_primal4<MODEL, MODE_STEPS_UPD, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else if (reduce) hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, true, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else hipLaunchKernelGGL((k_primal4<MODEL, MODE_UPDATE, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
 }
 
 template <int F>
 static void launch_primal4(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
-    if (g.model == MODEL_IC) launch_primal4_m<MODEL_IC, F>(g, a, t0, nf, mode, reduce, s);
-    else if (g.model == MODEL_K1) launch_primal4_m<MODEL_K1, F>(g, a, t0, nf, mode, reduce, s);
-    else launch_primal4_m<MODEL_ADD, F>(g, a, t0, nf, mode, reduce, s);
+    constexpr bool S4 = F == 4;        // the separable instances exist at zoom 4 only
+    if (S4 && g.sep) {
+        if (g.model == MODEL_IC) launch_primal4_m<MODEL_IC, F, S4>(g, a, t0, nf, mode, reduce, s);
+        else if (g.model == MODEL_K1) launch_primal4_m<MODEL_K1, F, S4>(g, a, t0, nf, mode, reduce, s);
+        else launch_primal4_m<MODEL_ADD, F, S4>(g, a, t0, nf, mode, reduce, s);
+        return;
+    }
+    if (g.model == MODEL_IC) launch_primal4_m<MODEL_IC, F, false>(g, a, t0, nf, mode, reduce, s);
+    else if (g.model == MODEL_K1) launch_primal4_m<MODEL_K1, F, false>(g, a, t0, nf, mode, reduce, s);
+    else launch_primal4_m<MODEL_ADD, F, false>(g, a, t0, nf, mode, reduce, s);
 }
 
 hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s) {
@@ -1428,27 +1557,33 @@ hipError_t mmc_launch_primal(const Geom &g, const Arrays &a, int t0, int t1, int
     return hipGetLastError();
 }
 
-template <int MODEL, int F>
+template <int MODEL, int F, bool SEPK>
 static void launch_dual4_m(const Geom &g0, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
     const Geom g = with_launch_frames(g0, nf);
     dim3 grid(8u * (unsigned)((g.ntiles + 7) / 8) * (unsigned)nf), block(MMC_THREADS);
     const int f = g.f;
     const int fe = (TILE_R % f == 0 && TILE_C % f == 0) ? f : 1;
     const int SRmax = g.SRp > TILE_R + g.CH - fe ? g.SRp : TILE_R + g.CH - fe;
-    const size_t lds = (size_t)(((SRmax * (TILE_C + g.CW - fe) + 3) & ~3) + (((MMC_THREADS / 64) * (TILE_R / f) * (TILE_C / f) + 3) & ~3) +
-                                g.MPq * g.CW + 2 * MMC_WARP_MAX) * sizeof(float) + lds_pad();
-    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F>), grid, block, lds, s, g, a, t0, nf);
-    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F>), grid, block, lds, s, g, a, t0, nf);
-    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F>), grid, block, lds, s, g, a, t0, nf);
-    else if (reduce) hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, true, F>), grid, block, lds, s, g, a, t0, nf);
-    else hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, false, F>), grid, block, lds, s, g, a, t0, nf);
+    const size_t lds = (size_t)(((SRmax * (TILE_C + g.CW - fe) + 3) & ~3) + dual_mid_floats(g, SEPK) + 2 * MMC_WARP_MAX) * sizeof(float) + lds_pad();
+    if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else if (reduce) hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, true, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
+    else hipLaunchKernelGGL((k_dual4<MODEL, MODE_UPDATE, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
 }
 
 template <int F>
 static void launch_dual4(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
-    if (g.model == MODEL_IC) launch_dual4_m<MODEL_IC, F>(g, a, t0, nf, mode, reduce, s);
-    else if (g.model == MODEL_K1) launch_dual4_m<MODEL_K1, F>(g, a, t0, nf, mode, reduce, s);
-    else launch_dual4_m<MODEL_ADD, F>(g, a, t0, nf, mode, reduce, s);
+    constexpr bool S4 = F == 4;
+    if (S4 && g.sep) {
+        if (g.model == MODEL_IC) launch_dual4_m<MODEL_IC, F, S4>(g, a, t0, nf, mode, reduce, s);
+        else if (g.model == MODEL_K1) launch_dual4_m<MODEL_K1, F, S4>(g, a, t0, nf, mode, reduce, s);
+        else launch_dual4_m<MODEL_ADD, F, S4>(g, a, t0, nf, mode, reduce, s);
+        return;
+    }
+    if (g.model == MODEL_IC) launch_dual4_m<MODEL_IC, F, false>(g, a, t0, nf, mode, reduce, s);
+    else if (g.model == MODEL_K1) launch_dual4_m<MODEL_K1, F, false>(g, a, t0, nf, mode, reduce, s);
+    else launch_dual4_m<MODEL_ADD, F, false>(g, a, t0, nf, mode, reduce, s);
 }
 
 hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int mode, bool reduce, hipStream_t s) {
@@ -1456,7 +1591,8 @@ hipError_t mmc_launch_dual(const Geom &g, const Arrays &a, int t0, int t1, int m
     const int nf = t1 - t0;
     if (a.ne > 0 && mode != MODE_STEPS) {
         const int total = a.ne * nf;
-        hipLaunchKernelGGL(k_corr_p, dim3((total + MMC_THREADS - 1) / MMC_THREADS), dim3(MMC_THREADS), 0, s, g, a, t0, nf);
+        const int per_block = MMC_THREADS / CORR_P_LANES;
+        hipLaunchKernelGGL(k_corr_p, dim3((total + per_block - 1) / per_block), dim3(MMC_THREADS), 0, s, g, a, t0, nf);
     }
     // regulariser duals and data-term dual in one launch
     if (g.f == 4) launch_dual4<4>(g, a, t0, nf, mode, reduce, s);

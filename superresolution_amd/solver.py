@@ -342,6 +342,11 @@ class FrameBlockSolver(object):
         """Bytes by which consecutive per-pixel planes are shifted against each other (placement only)."""
         return int(self._lib.mmc_debug_plane_skew(self._h))
 
+    @property
+    def separable(self):
+        """True when the sweeps apply the sampler-and-blur kernel as two 1-D passes (see mmc_debug_separable)."""
+        return bool(self._lib.mmc_debug_separable(self._h))
+
     def debug_steps_update(self):
         """tau_u, tau_w as the update sweep derives them (see mmc_debug_steps_update)."""
         N, L = self.Ny * self.Nx, self.L

@@ -89,6 +89,51 @@ def test_solve_parity(method, aa, ny, nx):
     assert abs(e - e_ref) <= 1e-3 * abs(e_ref)
 
 
+def _disc(n):
+    """A blur that is not an outer product: a disc of diameter n."""
+    y, x = np.mgrid[:n, :n] - (n - 1) / 2.0
+    k = (x * x + y * y <= (n / 2.0) ** 2).astype(np.float64)
+    return k / k.sum()
+
+
+@pytest.mark.parametrize("name,k,method", [("gaussian13", orc.fspecial_gaussian(13, 2.0), "average"),
+                                           ("disc11", _disc(11), "average"), ("disc11-bicubic", _disc(11), "bicubic"),
+                                           ("gaussian9x15", np.outer(orc.fspecial_gaussian(9, 1.5)[:, 4], orc.fspecial_gaussian(15, 2.5)[7, :]), "average")])
+def test_large_blur_kernels(name, k, method):
+    """Composite kernels beyond 3 x 3 low-res taps at zoom 4: a separable one is applied as two 1-D passes
+    (column sums of the low-res window, then the rows; row sums of the xbar window, then the columns), a
+    non-separable one from the full table.  40 x 28 low-res pixels: interior tiles, border tiles, and the
+    virtual rows and columns of the replicate border all take part."""
+    from superresolution_amd.solver import FrameBlockSolver
+    k = k / k.sum()
+    ny, nx, nc = 40, 28, 3
+    f, v, _ = make_case(74, ny, nx, nc, flow="smooth", flow_scale=1.5)
+    aa = method == "bicubic"
+    P = orc.build_problem(f, v, k=k, interpMethod=method, interpAA=aa)
+    if method == "average":
+        s = FrameBlockSolver(ny, nx, 4, nc, alpha=P.alpha, kappa=0.25, h=P.h, sampling="average")
+        s.set_lowres(f); s.set_blur(k); s.set_flow(v); s.set_state(P.u_up, P.u_up); s.init()
+    else:
+        s = _make(f, v, P, method, None, aa, k, 4)
+    assert s.separable == name.startswith("gaussian")
+    rng = np.random.default_rng(5)
+    Ny, Nx = P.dims[:2]
+    x = rng.normal(size=P.K.shape[1])
+    p, g1, g2 = s.debug_apply_K(x[:P.M].reshape((Ny, Nx, nc), order="F"), x[P.M:].reshape((Ny, Nx, nc), order="F"))
+    assert rel_l2(p, _split_y(P, P.K @ x)["p"]) < 3e-6
+    y = rng.normal(size=P.K.shape[0])
+    y[np.asarray(abs(P.K).sum(axis=1)).ravel() == 0] = 0
+    yb = _split_y(P, y)
+    ku, kw = s.debug_apply_KT(yb["p"], yb["g1"], yb["g2"])
+    assert rel_l2(ku, (P.KT @ y)[:P.M]) < 3e-6
+    assert rel_l2(s.debug_steps()[0], P.T[:P.M]) < 2e-6
+    s.solve(30, 0.0, 0)
+    u, w = s.get_state()
+    s.close()
+    xr, _, _ = orc.pdhg(P, 30)
+    assert rel_l2(u, orc.split_primal(P, xr)[0]) < 2e-5
+
+
 def test_mirror_class_with_bicubic_sampler():
     """The mirror of the MATLAB class with interpMethod = 'bicubic', interpAA = true."""
     from superresolution_amd import MultiframeMotionCoupling

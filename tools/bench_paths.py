@@ -1,6 +1,6 @@
 """Iteration time of the code paths beside the headline one, on 1080p-sized frames (10 frames each): other
 zoom factors, a row count that is not a multiple of 4 (short last row quads, unaligned columns), samplers
-handed over as rows.  usage: python tools/bench_paths.py [iters]"""
+handed over as rows.  usage: python tools/bench_paths.py [iters] [case number, to run that one only]"""
 import os
 import sys
 
@@ -21,6 +21,8 @@ CASES = [("zoom 4, 'average' (headline path)", 4, 270, 480, "average", None, Fal
          ("zoom 2, 'average' (4-tap mean), as rows", 2, 540, 960, "average", None, False),
          ("zoom 3, 'stride', 1080 rows", 3, 360, 640, "stride", None, False),
          ("zoom 3, 'stride', 1083 rows (no row quads)", 3, 361, 640, "stride", None, False)]
+if len(sys.argv) > 2:
+    CASES = [CASES[int(sys.argv[2])]]
 for name, factor, ny, nx, method, kernel, aa in CASES:
     Ny, Nx = factor * ny, factor * nx
     blk = synthetic.make_block(ny, nx, L, 0, L, factor=factor, device="cpu")
