@@ -618,6 +618,11 @@ __host__ __device__ inline int dual_mid_floats(const Geom &g, bool sep) {
     return (((TILE_R / 4) * (TILE_C + g.CW - 4) + 3) & ~3) + g.MPq + ((g.CW + 3) & ~3);
 }
 
+// Floats per plane of the tap regions.  The instances for separable kernels stage a larger data-term window
+// (their kernels are the large ones); with 256 floats less per tap region five of their workgroups still fit a
+// CU.  Tiles whose taps spread further gather them from global memory, as tiles beyond MMC_WARP_MAX always do.
+__host__ __device__ constexpr int dual_tap_floats(bool sep) { return sep ? MMC_WARP_MAX - 256 : MMC_WARP_MAX; }
+
 template <int MODEL, int MODE, bool REDUCE, int F, bool SEPK = false>
 __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual4(Geom g, Arrays a, int t0, int nf) {
     extern __shared__ __align__(16) float lds[];
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
     float *kys = sl + ((LRR * SC + 3) & ~3);            // ky shifted down by wpad rows, MPq floats
     float *kxs = kys + g.MPq;                           // kx, CW floats
     float *wu = SEPK ? psum + dual_mid_floats(g, true) : ckq + g.MPq * g.CW;      // tap region of the warped frame, xbar_u
-    float *ww = wu + MMC_WARP_MAX;                      // ... and xbar_w
+    float *ww = wu + dual_tap_floats(SEPK);             // ... and xbar_w
     const float *ub = FR(a.ub, t), *wb = FR(a.wb, t);
     const float *ubW = FR(a.ub, isIF ? t + 1 : t), *wbW = FR(a.wb, isIF ? t + 1 : t);   // warped frame
     // Rows/columns of the warped frame that this tile's taps touch (from mmc_init), rows widened
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
             // Odd pitch: a wave's 16 row quads x 4 columns read rows 4 apart, which an even pitch folds
             // onto 16 of the 64 LDS banks (4-way conflicts); with an odd pitch all 64 addresses differ mod 64.
             WP = WR + MMC_TAP_ODD_PITCH;
-            use_lds = WP * WC <= MMC_WARP_MAX;
+            use_lds = WP * WC <= dual_tap_floats(SEPK);
         }
     }
 
@@ -1564,7 +1569,7 @@ static void launch_dual4_m(const Geom &g0, const Arrays &a, int t0, int nf, int 
     const int f = g.f;
     const int fe = (TILE_R % f == 0 && TILE_C % f == 0) ? f : 1;
     const int SRmax = g.SRp > TILE_R + g.CH - fe ? g.SRp : TILE_R + g.CH - fe;
-    const size_t lds = (size_t)(((SRmax * (TILE_C + g.CW - fe) + 3) & ~3) + dual_mid_floats(g, SEPK) + 2 * MMC_WARP_MAX) * sizeof(float) + lds_pad();
+    const size_t lds = (size_t)(((SRmax * (TILE_C + g.CW - fe) + 3) & ~3) + dual_mid_floats(g, SEPK) + 2 * dual_tap_floats(SEPK)) * sizeof(float) + lds_pad();
     if (mode == MODE_RAW) hipLaunchKernelGGL((k_dual4<MODEL, MODE_RAW, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_STEPS) hipLaunchKernelGGL((k_dual4<MODEL, MODE_STEPS, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
     else if (mode == MODE_ENERGY) hipLaunchKernelGGL((k_dual4<MODEL, MODE_ENERGY, false, F, SEPK>), grid, block, lds, s, g, a, t0, nf);
