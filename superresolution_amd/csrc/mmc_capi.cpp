@@ -782,10 +782,11 @@ static int build_data_operator(mmc_handle *h) {
     HIPCHK(h, hipMemcpyAsync(h->a.ckq, ckq.data(), ckq.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     // Separable composite kernel (the samplers are products of two 1-D factors, samplingOperator.m:146; a
     // Gaussian blur is one as well): ck = ky kx' up to float32 rounding.  Worth two passes only beyond 3 x 3
-    // low-res taps.
+    // low-res taps at zoom 4, whose one-pass form has its taps unrolled; from MMC_SEP_MIN_TAPS low-res taps on
+    // at the other zoom factors.
     g.sep = 0;
     std::vector<float> ksep((size_t)3 * MMC_KSEP_PITCH, 0.f);
-    if (MMC_SEPARABLE && f == 4 && g.Jr * g.Jc > 9 && g.SRp <= 128 && g.MP <= MMC_KSEP_PITCH && g.NP <= MMC_KSEP_PITCH && g.MPq <= MMC_KSEP_PITCH) {
+    if (MMC_SEPARABLE && g.Jr * g.Jc >= (f == 4 ? MMC_SEP_MIN_TAPS4 : MMC_SEP_MIN_TAPS) && g.SRp <= 128 && g.MP <= MMC_KSEP_PITCH && g.NP <= MMC_KSEP_PITCH && g.MPq <= MMC_KSEP_PITCH) {
         size_t piv = 0;
         for (size_t i = 1; i < ck.size(); ++i) if (std::fabs(ck[i]) > std::fabs(ck[piv])) piv = i;
         const int pm = (int)(piv % (size_t)g.CH), pn = (int)(piv / (size_t)g.CH);

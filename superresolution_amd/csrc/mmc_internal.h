@@ -61,6 +61,12 @@ static inline FastDiv make_fastdiv(unsigned d) {
 #ifndef MMC_SEPARABLE
 #define MMC_SEPARABLE 1     // 0: never split a separable composite kernel into its two factors
 #endif
+#ifndef MMC_SEP_MIN_TAPS4
+#define MMC_SEP_MIN_TAPS4 10  // the same at zoom 4, whose one-pass form has 3 x 3 low-res taps unrolled with scalar weights
+#endif
+#ifndef MMC_SEP_MIN_TAPS
+#define MMC_SEP_MIN_TAPS 9    // zoom factors other than 4: low-res taps (Jr x Jc) from which a separable kernel takes two passes
+#endif
 #define MMC_KSEP_PITCH (MMC_MAX_CK + 8)       // floats between the three vectors of Arrays::ksep
 // identity bits (Arrays::idq): one byte per row quad, ceil(Ny / 4) quads per column, column after column
 #define MMC_IDQ_PER_FRAME(g) ((size_t)(((g).Ny + 3) >> 2) * (size_t)(g).Nx)

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
     float *ckp = lds + 6 * TILE_R * TILE_C;
     float *pl = ckp + ((g.MP * g.NP + 3) & ~3);
     // Separable composite kernel (Geom::sep): column sums of the low-res window per tile column, and the two factors
-    constexpr bool SEP = SEPK && F == 4 && MODE != MODE_STEPS && MODE != MODE_STEPS_UPD;    // the launcher picks SEPK from Geom::sep
+    constexpr bool SEP = SEPK && MODE != MODE_STEPS && MODE != MODE_STEPS_UPD;    // the launcher picks SEPK from Geom::sep
     float *tl = pl + ((g.PR * g.PC + 3) & ~3);          // PR x TILE_C
     float *kys = tl + ((g.PR * TILE_C + 3) & ~3);       // ky, MP floats (16-byte aligned)
     float *kxs = kys + g.MP;                            // kx, NP floats
@@ -321,8 +321,14 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
     // over the low-res columns, tl[row + PR * column] = sum_jc kx[phase + 4 jc] p[row, Chi - jc]; the first and
     // the last column of the frame add the virtual columns that the replicate border of the blur folds onto
     // them (helpers/RepConvMtx.m:23-32).  Done here, after the scatter, where few registers are live.
+    // low-res index and kernel phase of a kernel coordinate x >= 0 (x = 4 q + phase at zoom 4)
+    const float inv_f = fast_rcp((float)f);
+    auto lr_of = [&](int x, int &q, int &phase) {
+        if (F == 4) { q = x >> 2; phase = x & 3; }
+        else { q = (int)(((float)x + 0.5f) * inv_f); phase = x - f * q; }
+    };
     if (SEP) {
-        const int cvlast = max(4 * (g.nx - 1) + g.ox + g.CW - 1, g.Nx - 1);
+        const int cvlast = max(f * (g.nx - 1) + g.ox + g.CW - 1, g.Nx - 1);
 #pragma unroll 1
         for (int k = tid; k < g.PR * TILE_C; k += MMC_THREADS) {
             const int cl = fdiv(k, g.dv_PR), pr = k - cl * g.PR;
@@ -331,11 +337,12 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
             float sacc = 0.f;
 #pragma unroll 1
             for (int cv = cvA; cv <= cvB; ++cv) {
-                const int xcv = cv - g.ox;
-                const float *pp = pl + pr + g.PR * ((xcv >> 2) - Cbase);
-                const float *kw = kxs + (xcv & 3);
+                int Chv, bcv;
+                lr_of(cv - g.ox, Chv, bcv);
+                const float *pp = pl + pr + g.PR * (Chv - Cbase);
+                const float *kw = kxs + bcv;
 #pragma unroll 1
-                for (int jc = 0; jc < g.Jc; ++jc) sacc += kw[4 * jc] * pp[-g.PR * jc];
+                for (int jc = 0; jc < g.Jc; ++jc) sacc += kw[f * jc] * pp[-g.PR * jc];
             }
             tl[k] = sacc;
         }
@@ -424,23 +431,24 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
                             s += wk[br + 4 * jr + 48 * jc] * pv[dR - jr + 2][jc];
                     ATp[i] = s;
                 }
-            } else if (SEP && (r == 0 || r + 4 >= g.Ny)) {
-                // second factor for the quads with the first or the last row of the frame: that row adds the
-                // virtual rows folded onto it
-                const int rvlast = max(4 * (g.ny - 1) + g.oy + g.CH - 1, g.Ny - 1);
+            } else if (SEP && (F != 4 || r == 0 || r + 4 >= g.Ny)) {
+                // second factor row by row: every quad at the other zoom factors, and at zoom 4 the quads with the
+                // first or the last row of the frame, which adds the virtual rows folded onto it
+                const int rvlast = max(f * (g.ny - 1) + g.oy + g.CH - 1, g.Ny - 1);
                 const float *tcl = tl + g.PR * lc - Rbase;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int ri = r + i;
-                    const int rv0 = ri == 0 ? min(g.oy, 0) : ri, rv1 = ri == g.Ny - 1 ? rvlast : ri;
+                    const int rv0 = ri == 0 ? min(g.oy, 0) : ri, rv1 = ri == g.Ny - 1 ? rvlast : (i < nv ? ri : ri - 1);
                     float sacc = 0.f;
 #pragma unroll 1
                     for (int rv = rv0; rv <= rv1; ++rv) {
-                        const int x = rv - g.oy;
-                        const float *tc = tcl + (x >> 2);
-                        const float *kw = kys + (x & 3);
+                        int Rhv, brv;
+                        lr_of(rv - g.oy, Rhv, brv);
+                        const float *tc = tcl + Rhv;
+                        const float *kw = kys + brv;
 #pragma unroll 1
-                        for (int jr = 0; jr < g.Jr; ++jr) sacc += kw[4 * jr] * tc[-jr];
+                        for (int jr = 0; jr < g.Jr; ++jr) sacc += kw[f * jr] * tc[-jr];
                     }
                     ATp[i] = sacc;
                 }
@@ -614,8 +622,11 @@ __global__ __launch_bounds__(MMC_THREADS, MMC_OCC_PRIMAL) void k_primal4(Geom g,
 // kernel table, or (separable kernel at zoom 4) the row sums of the window and the two factors.
 __host__ __device__ inline int dual_mid_floats(const Geom &g, bool sep) {
     const int f = g.f;
-    if (!sep) return (((MMC_THREADS / 64) * (TILE_R / f) * (TILE_C / f) + 3) & ~3) + g.MPq * g.CW;
-    return (((TILE_R / 4) * (TILE_C + g.CW - 4) + 3) & ~3) + g.MPq + ((g.CW + 3) & ~3);
+    const int psum = ((MMC_THREADS / 64) * (TILE_R / f) * (TILE_C / f) + 3) & ~3;
+    if (!sep) return psum + g.MPq * g.CW;
+    const int fe = (TILE_R % f == 0 && TILE_C % f == 0) ? f : 1;
+    const int sums = ((((TILE_R + f - 1) / f) * (TILE_C + g.CW - fe) + 3) & ~3) + g.MPq + ((g.CW + 3) & ~3);
+    return sums > psum ? sums : psum;
 }
 
 // Floats per plane of the tap regions.  The instances for separable kernels stage a larger data-term window
@@ -653,9 +664,9 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
     float *ckq = psum + ((NWV * nlr + 3) & ~3);         // composite kernel shifted down by wpad rows, MPq x CW
     // Separable composite kernel (Geom::sep): the row sums of the window and the two factors take the place of
     // the partial sums and the kernel table
-    const bool SEP = SEPK && F == 4 && VEC;             // the launcher picks SEPK from Geom::sep
-    float *sl = psum;                                   // LRR x SC: sum_m ky[m] window[4 R + m, column]
-    float *kys = sl + ((LRR * SC + 3) & ~3);            // ky shifted down by wpad rows, MPq floats
+    const bool SEP = SEPK && VEC;                       // the launcher picks SEPK from Geom::sep
+    float *sl = psum;                                   // low-res rows of the tile x SC: sum_m ky[m] window[f R + m, column]
+    float *kys = sl + ((((TILE_R + f - 1) / f) * SC + 3) & ~3);      // ky shifted down by wpad rows, MPq floats
     float *kxs = kys + g.MPq;                           // kx, CW floats
     float *wu = SEPK ? psum + dual_mid_floats(g, true) : ckq + g.MPq * g.CW;      // tap region of the warped frame, xbar_u
     float *ww = wu + dual_tap_floats(SEPK);             // ... and xbar_w
@@ -1027,6 +1038,29 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
         const int nlrt = LRRt * LRCt;
         const int sub = tid & (LPP - 1);
         const float inv_lrr = fast_rcp((float)max(LRRt, 1));
+        if (SEP && MODE != MODE_STEPS) {
+            // separable kernel: first factor down the rows of every window column for the tile's low-res rows
+            const int nout = LRRt * SC;
+#pragma unroll 1
+            for (int k = tid; k < nout; k += MMC_THREADS) {
+                int cc = (int)(((float)k + 0.5f) * inv_lrr);
+                int Rl = k - cc * LRRt;
+                if (Rl < 0) { --cc; Rl += LRRt; }
+                if (Rl >= LRRt) { ++cc; Rl -= LRRt; }
+                const float *col = ubl + (f * (LR0 + Rl) - r0) + SR * cc;
+                float sr = 0.f;
+                if ((f & 1) == 0) {
+                    const float2 *c2 = reinterpret_cast<const float2 *>(col), *k2 = reinterpret_cast<const float2 *>(kys);
+#pragma unroll 1
+                    for (int m = 0; m < (g.MPq >> 1); ++m) sr += k2[m].x * c2[m].x + k2[m].y * c2[m].y;
+                } else {
+#pragma unroll 1
+                    for (int mm = 0; mm < g.CH; ++mm) sr += kys[wpad + mm] * col[wpad + mm];
+                }
+                sl[Rl + LRRt * cc] = sr;
+            }
+            __syncthreads();
+        }
         for (int lp = tid / LPP; lp < nlrt; lp += MMC_THREADS / LPP) {
             int Cl = (int)(((float)lp + 0.5f) * inv_lrr);
             int Rl = lp - Cl * LRRt;
@@ -1044,7 +1078,11 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
             }
             const float *win = ubl + (f * R - r0) + SR * (f * C - c0);          // window row of kernel row -wpad
             float s = 0.f;
-            if ((f & 1) == 0) {
+            if (SEP) {
+                const float *srow = sl + Rl + LRRt * (f * C - c0);
+#pragma unroll 1
+                for (int nn = sub; nn < g.CW; nn += LPP) s += kxs[nn] * srow[LRRt * nn];
+            } else if ((f & 1) == 0) {
                 // even zoom: these rows start on an even row of the window: 8-byte reads against the
                 // kernel table that is shifted down by the padding rows
                 const int m2 = g.MPq >> 1;
@@ -1539,11 +1577,10 @@ static void launch_primal4_m(const Geom &g0, const Arrays &a, int t0, int nf, in
 
 template <int F>
 static void launch_primal4(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
-    constexpr bool S4 = F == 4;        // the separable instances exist at zoom 4 only
-    if (S4 && g.sep) {
-        if (g.model == MODEL_IC) launch_primal4_m<MODEL_IC, F, S4>(g, a, t0, nf, mode, reduce, s);
-        else if (g.model == MODEL_K1) launch_primal4_m<MODEL_K1, F, S4>(g, a, t0, nf, mode, reduce, s);
-        else launch_primal4_m<MODEL_ADD, F, S4>(g, a, t0, nf, mode, reduce, s);
+    if (g.sep) {
+        if (g.model == MODEL_IC) launch_primal4_m<MODEL_IC, F, true>(g, a, t0, nf, mode, reduce, s);
+        else if (g.model == MODEL_K1) launch_primal4_m<MODEL_K1, F, true>(g, a, t0, nf, mode, reduce, s);
+        else launch_primal4_m<MODEL_ADD, F, true>(g, a, t0, nf, mode, reduce, s);
         return;
     }
     if (g.model == MODEL_IC) launch_primal4_m<MODEL_IC, F, false>(g, a, t0, nf, mode, reduce, s);
@@ -1579,11 +1616,10 @@ static void launch_dual4_m(const Geom &g0, const Arrays &a, int t0, int nf, int 
 
 template <int F>
 static void launch_dual4(const Geom &g, const Arrays &a, int t0, int nf, int mode, bool reduce, hipStream_t s) {
-    constexpr bool S4 = F == 4;
-    if (S4 && g.sep) {
-        if (g.model == MODEL_IC) launch_dual4_m<MODEL_IC, F, S4>(g, a, t0, nf, mode, reduce, s);
-        else if (g.model == MODEL_K1) launch_dual4_m<MODEL_K1, F, S4>(g, a, t0, nf, mode, reduce, s);
-        else launch_dual4_m<MODEL_ADD, F, S4>(g, a, t0, nf, mode, reduce, s);
+    if (g.sep) {
+        if (g.model == MODEL_IC) launch_dual4_m<MODEL_IC, F, true>(g, a, t0, nf, mode, reduce, s);
+        else if (g.model == MODEL_K1) launch_dual4_m<MODEL_K1, F, true>(g, a, t0, nf, mode, reduce, s);
+        else launch_dual4_m<MODEL_ADD, F, true>(g, a, t0, nf, mode, reduce, s);
         return;
     }
     if (g.model == MODEL_IC) launch_dual4_m<MODEL_IC, F, false>(g, a, t0, nf, mode, reduce, s);
