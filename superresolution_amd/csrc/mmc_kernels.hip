@@ -96,6 +96,9 @@ __device__ __forceinline__ void st4m(float *p, const float (&s)[4], int nv) {
 #ifndef MMC_ATP_QUAD
 #define MMC_ATP_QUAD 1          // zoom 4, kernels beyond 3 x 3 low-res taps: A'p of a row quad with 16-byte weight reads
 #endif
+#ifndef MMC_DUAL_UC_LDS
+#define MMC_DUAL_UC_LDS 1         // 1: the quad's own xbar_u comes from the staged data-term window as well
+#endif
 #ifndef MMC_OCC_DUAL
 #define MMC_OCC_DUAL 1
 #endif
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
     float ubelow = 0.f, wbelow = 0.f;
     if (active) {
         if (pex) { ld4(fvx, FR(a.vx, t) + j); ld4(fvy, FR(a.vy, t) + j); }
-        ld4(uc, ub + j);
+        if (!(MMC_DUAL_UC_LDS && nb_lds)) ld4(uc, ub + j);
         if (!nb_lds) {
             if (hasx) ld4(ux, ub + j + g.Ny);
             if (r + 4 < g.Ny) ubelow = ub[j + 4];
@@ -790,6 +793,7 @@ __global__ __launch_bounds__(MMC_THREADS, F == 4 ? MMC_OCC_DUAL : 5) void k_dual
     float diag[2] = {0.f, 0.f};      // MODE_ENERGY: |K x|^2, dual optimality residual^2
     if (active && nb_lds) {
         const float *own = ubl + (4 * rq - g.oy + wpad) + SR * (lc - g.ox);
+        if (MMC_DUAL_UC_LDS) ld4(uc, own);
         if (hasx) ld4(ux, own + SR);
         if (r + 4 < g.Ny) ubelow = own[4];
     }
