@@ -20,7 +20,9 @@ CASES = [("zoom 4, 'average' (headline path)", 4, 270, 480, "average", None, Fal
          ("zoom 2, 'stride'", 2, 540, 960, "stride", None, False),
          ("zoom 2, 'average' (4-tap mean), as rows", 2, 540, 960, "average", None, False),
          ("zoom 3, 'stride', 1080 rows", 3, 360, 640, "stride", None, False),
-         ("zoom 3, 'stride', 1083 rows (no row quads)", 3, 361, 640, "stride", None, False)]
+         ("zoom 3, 'stride', 1083 rows (no row quads)", 3, 361, 640, "stride", None, False),
+         ("zoom 8, 'stride'", 8, 135, 240, "stride", None, False),
+         ("zoom 4, 'bicubic' without anti-aliasing, as rows", 4, 270, 480, "bicubic", None, False)]
 if len(sys.argv) > 2:
     CASES = [CASES[int(sys.argv[2])]]
 for name, factor, ny, nx, method, kernel, aa in CASES:
