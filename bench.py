@@ -269,6 +269,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
+    # ranks that share device buffers (RCCL) need the dmabuf IPC mode of this driver stack; set before the runtime loads
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # whatever may start a child process (make for the C restatement) happens before the GPU runtime is loaded
     have_c = c_oracle_ready() if (world == 1 and not args.no_cpu_baseline) else False
 
