@@ -82,6 +82,61 @@ def test_one_rank_over_rccl(tmp_path):
     _run_and_check(tmp_path, 1, 4, 0.25, "backward", "nccl")
 
 
+def _self_exchange_worker(rank, world, port, out_dir):
+    """One rank, RCCL, a middle block of a longer sequence: the frames it would send to its neighbours go to
+    its own ghost slots instead (RCCL accepts a send and a receive of one rank to itself in one batch)."""
+    import torch
+    import torch.distributed as dist
+    from superresolution_amd import sharding
+    from superresolution_amd.solver import FrameBlockSolver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        torch.cuda.set_stream(torch.cuda.Stream())
+        nc, a, b = 6, 2, 4
+        f, v, occ = make_case(43, 8, 10, nc, flow="smooth", flow_scale=2.0, with_occ=True)
+        P = orc.build_problem(f, v, k=KBLUR, occ=occ)
+        lo, hi = sharding.pairs_needed(a, b, nc)
+        s0, s1 = sharding.state_frames_needed(a, b, nc)
+        s = FrameBlockSolver(8, 10, 4, nc, a, b, alpha=P.alpha, kappa=0.25, h=P.h, device=0,
+                             stream=torch.cuda.current_stream().cuda_stream)
+        s.set_lowres(f[:, :, a:b]); s.set_blur(KBLUR); s.set_flow(v[:, :, lo:hi, :], occ[:, :, lo:hi])
+        s.set_state(P.u_up[:, :, s0:s1], P.u_up[:, :, s0:s1]); s.init()
+        t = sharding.halo_tensors(s)
+        ok = True
+        for it in range(3):
+            # the sweeps are queued on torch's current stream; the exchange is posted right behind them without a
+            # host synchronisation, as solve_sharded does
+            s.sweep_primal(0, b - a)
+            ops = [dist.P2POp(dist.isend, x, 0) for x in t["send_prev"]] + [dist.P2POp(dist.irecv, x, 0) for x in t["recv_next"]]
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            s.sweep_dual(0, b - a)
+            ops = [dist.P2POp(dist.isend, x, 0) for x in t["send_next"]] + [dist.P2POp(dist.irecv, x, 0) for x in t["recv_prev"]]
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            torch.cuda.synchronize()
+            for sname, rname in (("send_prev", "recv_next"), ("send_next", "recv_prev")):
+                for x, y in zip(t[sname], t[rname]):
+                    ok = ok and bool(torch.equal(x, y)) and bool(torch.isfinite(x).all())
+            ok = ok and float(t["send_prev"][0].abs().max()) > 0
+        np.savez(os.path.join(out_dir, "self.npz"), ok=ok)
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_moves_library_frames_on_one_gpu(tmp_path):
+    """The device-to-device transfer of the halo frames over RCCL, on the one GPU every box has: the buffers are
+    the library's own allocations (not torch's), the transfers are ordered against the sweeps by the stream alone."""
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    spawn_ranks("test_gpu_multiprocess", "_self_exchange_worker", (1, port, str(tmp_path)), 1)
+    assert bool(np.load(os.path.join(str(tmp_path), "self.npz"))["ok"])
+
+
 def _run_and_check(tmp_path, world, nc, kappa, direction, backend):
     iters = 30
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
