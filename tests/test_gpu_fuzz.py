@@ -41,3 +41,12 @@ def test_random_cuts_into_frame_blocks():
     res = spawn.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_group.py"), "150", "31"], timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "misses 0" in res.stdout
+
+
+def test_random_sampler_configurations():
+    """tools/fuzz_samplers.py: every sampler of helpers/samplingOperator.m handed over as rows, zoom 2 to 4, with and
+    without anti-aliasing and blur (composite kernels applied in one pass and, where separable and large, in two):
+    operators, step sizes and 15 iterations against the explicit sparse operators of the Python oracle."""
+    res = spawn.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_samplers.py"), "40", "51"], timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "misses 0" in res.stdout
