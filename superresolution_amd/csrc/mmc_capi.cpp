@@ -442,11 +442,12 @@ int mmc_internal_create_geometry(const mmc_params *p, mmc_handle **out) { return
 
 extern "C" int mmc_destroy(mmc_handle *h) {
     if (!h) return MMC_OK;
-    hipSetDevice(h->prm.device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    for (void *p : h->allocs) hipFree(p);
-    for (void *p : h->eallocs) hipFree(p);
-    if (h->a.ovf_idx) hipFree(h->a.ovf_idx);
+    // tear-down: nothing useful can be done about a failing release
+    (void)hipSetDevice(h->prm.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (void *p : h->eallocs) (void)hipFree(p);
+    if (h->a.ovf_idx) (void)hipFree(h->a.ovf_idx);
     for (hipEvent_t e : h->events) mmc_pool_event_release(h->prm.device, true, e);
     for (hipEvent_t e : h->sweep_events) mmc_pool_event_release(h->prm.device, true, e);
     if (h->own_stream && h->stream) mmc_pool_stream_release(h->prm.device, h->stream);      // idle: synchronised above
@@ -536,7 +537,7 @@ int mmc_internal_set_flow_planes(mmc_handle *h, const float *vcol, const float *
             hipError_t e = hipMemcpyAsync(docc, occ, cnt, hipMemcpyHostToDevice, h->stream);
             if (e == hipSuccess) e = mmc_launch_fold_occ(g, dvx, docc, cnt, h->stream);
             hipError_t e2 = hipStreamSynchronize(h->stream);
-            hipFree(docc);
+            (void)hipFree(docc);
             HIPCHK(h, e);
             HIPCHK(h, e2);
         }
@@ -687,7 +688,7 @@ static int analyse_axis(mmc_handle *h, AxisOp &ax, int f, int nout, int nin) {
 }
 
 static void free_correction(mmc_handle *h) {
-    for (void *p : h->eallocs) hipFree(p);
+    for (void *p : h->eallocs) (void)hipFree(p);
     h->eallocs.clear();
     Arrays &a = h->a;
     a.ne = a.net = 0;

@@ -99,7 +99,7 @@ extern "C" int mmc_group_destroy(mmc_group *g) {
         if (!b.h) continue;                 // never created: no stream, no events
         if (hipSetDevice(b.device) != hipSuccess) (void)hipGetLastError();
         // streams and events go back to the per-device pool (they live as long as the process)
-        if (b.copy) { hipStreamSynchronize(b.copy); mmc_pool_stream_release(b.device, b.copy); }
+        if (b.copy) { (void)hipStreamSynchronize(b.copy); mmc_pool_stream_release(b.device, b.copy); }
         for (hipEvent_t e : {b.primal_done, b.dual_done, b.xbar_sent, b.duals_sent}) mmc_pool_event_release(b.device, false, e);
         if (b.h) mmc_destroy(b.h);
     }
@@ -180,8 +180,8 @@ extern "C" int mmc_group_create(const mmc_params *p, int nblocks, const int32_t 
         const int da = g->blocks[i].device, db = g->blocks[i + 1].device;
         if (da == db) continue;
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) { hipSetDevice(da); (void)hipDeviceEnablePeerAccess(db, 0); }
-        if (hipDeviceCanAccessPeer(&can, db, da) == hipSuccess && can) { hipSetDevice(db); (void)hipDeviceEnablePeerAccess(da, 0); }
+        if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) { (void)hipSetDevice(da); (void)hipDeviceEnablePeerAccess(db, 0); }
+        if (hipDeviceCanAccessPeer(&can, db, da) == hipSuccess && can) { (void)hipSetDevice(db); (void)hipDeviceEnablePeerAccess(da, 0); }
         (void)hipGetLastError();      // "already enabled" is fine
     }
     *out = g;

@@ -63,9 +63,9 @@ extern "C" const char *mmc_sf_last_error(const mmc_sf_handle *h) { return h ? h-
 
 extern "C" int mmc_sf_destroy(mmc_sf_handle *h) {
     if (!h) return MMC_OK;
-    hipSetDevice(h->prm.device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    for (void *p : h->allocs) hipFree(p);
+    (void)hipSetDevice(h->prm.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
     if (h->geo) mmc_destroy(h->geo);
     delete h;
     return MMC_OK;
