@@ -129,6 +129,77 @@ def _self_exchange_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _two_blocks_worker(rank, world, port, kappa, direction, out_dir):
+    """One rank, RCCL, two frame blocks of one sequence on the same GPU: every halo frame travels as an RCCL
+    send matched by a receive of the same rank, in the order solve_sharded posts them for two ranks; nothing
+    but the stream orders the transfers against the sweeps."""
+    import torch
+    import torch.distributed as dist
+    from superresolution_amd import sharding
+    from superresolution_amd.solver import FrameBlockSolver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        torch.cuda.set_stream(torch.cuda.Stream())
+        nc, iters = 6, 30
+        f, v, occ = make_case(44, 8, 10, nc, flow="smooth", flow_scale=2.0, with_occ=True)
+        P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
+        blocks = []
+        for a, b in sharding.partition_frames(nc, 2):
+            lo, hi = sharding.pairs_needed(a, b, nc)
+            s0, s1 = sharding.state_frames_needed(a, b, nc)
+            s = FrameBlockSolver(8, 10, 4, nc, a, b, alpha=P.alpha, kappa=kappa, h=P.h, flow_direction=direction, device=0,
+                                 stream=torch.cuda.current_stream().cuda_stream)
+            s.set_lowres(f[:, :, a:b]); s.set_blur(KBLUR); s.set_flow(v[:, :, lo:hi, :], occ[:, :, lo:hi])
+            s.set_state(P.u_up[:, :, s0:s1], P.u_up[:, :, s0:s1]); s.init()
+            blocks.append((s, sharding.halo_tensors(s), b - a))
+        (A, tA, LA), (B, tB, LB) = blocks
+
+        def move(src, dst):
+            ops = [dist.P2POp(dist.isend, x, 0) for x in src if x is not None] + [dist.P2POp(dist.irecv, x, 0) for x in dst if x is not None]
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+
+        for it in range(iters):
+            A.sweep_primal(0, LA)
+            B.sweep_primal(0, LB)
+            move(tB["send_prev"], tA["recv_next"])          # xbar of B's first frame -> A's ghost
+            A.sweep_dual(0, LA)
+            B.sweep_dual(0, LB)
+            move(tA["send_next"], tB["recv_prev"])          # temporal duals of A's last frame -> B's ghost
+        torch.cuda.synchronize()
+        uA, wA = A.get_state()
+        uB, wB = B.get_state()
+        u = np.concatenate([uA, uB], axis=2)
+        out = {"u": u}
+        if wA is not None:
+            out["w"] = np.concatenate([wA, wB], axis=2)
+        np.savez(os.path.join(out_dir, "two.npz"), **out)
+        A.close(); B.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kappa,direction", [(0.25, "backward"), (float("nan"), "forward-backward"), (0.25, "forward")])
+def test_two_blocks_exchange_over_rccl_on_one_gpu(tmp_path, kappa, direction):
+    """A sequence in two frame blocks whose halo frames travel over RCCL (one rank, sends matched by its own
+    receives), against the single-block oracle: the device-to-device branch of the sharded solve on one GPU."""
+    iters = 30
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    spawn_ranks("test_gpu_multiprocess", "_two_blocks_worker", (1, port, kappa, direction, str(tmp_path)), 1)
+    f, v, occ = make_case(44, 8, 10, 6, flow="smooth", flow_scale=2.0, with_occ=True)
+    P = orc.build_problem(f, v, kappa=kappa, flowDirection=direction, k=KBLUR, occ=occ)
+    x, _, _ = orc.pdhg(P, iters)
+    u_ref, w_ref = orc.split_primal(P, x)
+    d = np.load(os.path.join(str(tmp_path), "two.npz"))
+    assert rel_l2(d["u"], u_ref) < 1e-4
+    if w_ref is not None:
+        assert np.abs(d["w"] - w_ref).max() < 1e-4
+
+
 def test_rccl_moves_library_frames_on_one_gpu(tmp_path):
     """The device-to-device transfer of the halo frames over RCCL, on the one GPU every box has: the buffers are
     the library's own allocations (not torch's), the transfers are ordered against the sweeps by the stream alone."""
