@@ -90,7 +90,7 @@ def test_gap_is_nonnegative_where_the_dual_is_feasible_and_shrinks():
         s.close()
 
 
-@pytest.mark.parametrize("case", ["zoom2", "zoom3", "rows_not_multiple_of_4", "fixed_frame"])
+@pytest.mark.parametrize("case", ["zoom2", "zoom3", "rows_not_multiple_of_4", "fixed_frame", "two_pass_kernel"])
 def test_diagnostics_on_the_other_kernel_paths(case):
     from superresolution_amd import _capi
     kw = {}
@@ -104,6 +104,9 @@ def test_diagnostics_on_the_other_kernel_paths(case):
     elif case == "rows_not_multiple_of_4":
         f, v, occ = make_case(75, 13, 10, 3, factor=3, flow="smooth", flow_scale=1.5)      # 39 rows
         factor, sampling = 3, "stride"
+    elif case == "two_pass_kernel":
+        f, v, occ = make_case(77, 24, 20, 3, flow="smooth", flow_scale=1.5)
+        k = orc.fspecial_gaussian(13, 2.0)             # 16 x 16 composite kernel at zoom 4: applied as two 1-D passes
     else:
         f, v, occ = make_case(76, 16, 12, 3, flow="smooth", flow_scale=1.5)
         rng = np.random.default_rng(1)
@@ -113,6 +116,7 @@ def test_diagnostics_on_the_other_kernel_paths(case):
     if kw:
         s.set_fixed_frame(kw["u0_frame"], kw["w0_frame"])
     s.init()
+    assert s.separable == (case in ("zoom2", "rows_not_multiple_of_4", "two_pass_kernel"))
     s.set_diagnostics(_capi.DIAG_ALWAYS)
     st = s.solve(40, 0.0, 0)
     x, y, _ = orc.pdhg(P, 40)
